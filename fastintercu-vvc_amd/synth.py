@@ -1,0 +1,213 @@
+"""Deterministic synthetic weights and CU patches (counter-based RNG).
+
+Nothing here comes from the reference: the reference ships no trained weights
+(`/root/reference/.MISSING_LARGE_BLOBS:7`) and no test vectors, so
+parity fixtures, GPU tests and bench.py all regenerate the SAME weights / inputs from
+integer seeds with this module.  The generator is a pure function of
+(seed, stream-name, index) so tensors can be produced in any order, on any rank.
+
+Distributions follow SURVEY.md §8(d):
+  conv weights  Kaiming-normal, fan_out, relu gain   (mlt_ctu_or_pq_arch.py:258-260)
+  BN            gamma~U(0.5,1.5) beta~N(0,0.1) mean~N(0,0.1) var~U(0.5,1.5)
+                (NOT the identity init of :261-263 - identity BN would hide folding bugs)
+  heads         U(+-1/sqrt(fan_in)) like nn.Linear's default
+  patches       10-bit luma `org`, `pred = clip(org + noise)` as int16 ("Pel", TypeDef.h:277)
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array."""
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def raw_u64(seed: int, stream: str, n: int, offset: int = 0) -> np.ndarray:
+    """n 64-bit words of stream `stream` under `seed`, starting at counter `offset`."""
+    key = _mix(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0] ^ np.uint64(_fnv1a64(stream))
+    key = _mix(np.array([key], dtype=np.uint64))[0]
+    ctr = np.arange(offset, offset + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return _mix(key + ctr * np.uint64(0xD1342543DE82EF95))
+
+
+def uniform(seed: int, stream: str, n: int, offset: int = 0) -> np.ndarray:
+    """float64 uniform in [0,1)."""
+    return (raw_u64(seed, stream, n, offset) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed: int, stream: str, n: int) -> np.ndarray:
+    """float64 standard normal (Box-Muller on two sub-streams)."""
+    u1 = uniform(seed, stream + "#a", n)
+    u2 = uniform(seed, stream + "#b", n)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def randint(seed: int, stream: str, n: int, lo: int, hi: int, offset: int = 0) -> np.ndarray:
+    """int64 uniform in [lo, hi] inclusive."""
+    span = np.uint64(hi - lo + 1)
+    return (raw_u64(seed, stream, n, offset) % span).astype(np.int64) + lo
+
+
+# --------------------------------------------------------------------------------------
+# architecture tables (arithmetic spec: mlt_ctu_or_pq_arch.py:239-299, mlt_cu_or_pq_arch.py:59-128)
+# --------------------------------------------------------------------------------------
+ARCH_CTU = 0  # MltCnnL3ORPQv4 / GapBigMltCtuORPQ  (128x128)
+ARCH_CU = 1   # MltCnnL4ORPQv4 / GapBigMltCuORPQ   (64/32/16)
+
+STAGE_PLANES = {ARCH_CTU: (32, 64, 128, 256), ARCH_CU: (32, 64, 96, 128, 256)}
+HEAD_CLASSES = {ARCH_CTU: (2, 3, 4), ARCH_CU: (2, 3, 4, 6)}
+STEM_PLANES = 32
+
+
+def arch_for_size(size: int) -> int:
+    """EncCu.cpp:897-899 picks the model file by cuw: 128 -> CTU arch, 64/32/16 -> CU arch."""
+    if size == 128:
+        return ARCH_CTU
+    if size in (64, 32, 16):
+        return ARCH_CU
+    raise ValueError(f"unsupported CU size {size}")
+
+
+def state_dict_spec(arch: int) -> "OrderedDict[str, tuple]":
+    """Ordered {state_dict key: shape} exactly as the reference module registers them
+    (checked against the imported reference in tools/gen_golden.py)."""
+    spec: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def bn(prefix, c):
+        spec[prefix + ".weight"] = (c,)
+        spec[prefix + ".bias"] = (c,)
+        spec[prefix + ".running_mean"] = (c,)
+        spec[prefix + ".running_var"] = (c,)
+        spec[prefix + ".num_batches_tracked"] = ()
+
+    spec["conv1.weight"] = (STEM_PLANES, 2, 3, 3)
+    bn("bn1", STEM_PLANES)  # registered but never applied (mlt_ctu_or_pq_arch.py:247,277-278)
+    planes = STAGE_PLANES[arch]
+    heads = HEAD_CLASSES[arch]
+    cin = STEM_PLANES
+    for li, c in enumerate(planes):
+        if li >= 1:
+            pass
+        for bi in range(2):
+            p = f"layer{li}.{bi}"
+            spec[p + ".conv1.weight"] = (c, cin if bi == 0 else c, 3, 3)
+            bn(p + ".bn1", c)
+            spec[p + ".conv2.weight"] = (c, c, 3, 3)
+            bn(p + ".bn2", c)
+            if bi == 0:  # stride 2 => projection shortcut, every stage (arch:44-50)
+                spec[p + ".shortcut.0.weight"] = (c, cin, 1, 1)
+                bn(p + ".shortcut.1", c)
+        cin = c
+        if li >= 1:
+            spec[f"branch{li}.weight"] = (heads[li - 1], c + 2)
+            spec[f"branch{li}.bias"] = (heads[li - 1],)
+    return spec
+
+
+def _module_order_spec(arch: int) -> "OrderedDict[str, tuple]":
+    """Same keys, in torch's registration order (branchN sits between layers in the ctor)."""
+    return state_dict_spec(arch)
+
+
+def make_state_dict(arch: int, weight_seed: int, head_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic fp32 state_dict with non-trivial BN statistics."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for key, shape in state_dict_spec(arch).items():
+        n = int(np.prod(shape)) if shape else 1
+        if key.endswith("num_batches_tracked"):
+            sd[key] = np.array(1000, dtype=np.int64)
+            continue
+        if key.endswith("running_var"):
+            v = 0.5 + uniform(weight_seed, key, n)
+        elif key.endswith("running_mean"):
+            v = 0.1 * normal(weight_seed, key, n)
+        elif ".bn" in key or "shortcut.1" in key or key.startswith("bn1"):
+            if key.endswith(".weight"):
+                v = 0.5 + uniform(weight_seed, key, n)
+            else:
+                v = 0.1 * normal(weight_seed, key, n)
+        elif key.startswith("branch"):
+            fan_in = shape[-1] if key.endswith(".weight") else state_dict_spec(arch)[key[:-4] + "weight"][-1]
+            bound = head_scale / math.sqrt(fan_in)
+            v = (2.0 * uniform(weight_seed, key, n) - 1.0) * bound
+        else:  # conv weight [Cout, Cin, kh, kw]: kaiming_normal_(mode='fan_out', relu)
+            fan_out = shape[0] * shape[2] * shape[3]
+            v = normal(weight_seed, key, n) * math.sqrt(2.0 / fan_out)
+        sd[key] = v.astype(np.float32).reshape(shape)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# CU patches
+# --------------------------------------------------------------------------------------
+KIND_TEXTURE = 0     # blocky base + texture, pred = org + noise[-40,40]   (bench workload)
+KIND_UNIFORM = 1     # i.i.d. uniform 10-bit org and pred
+KIND_ZERO_RESI = 2   # pred == org  (all-zero residual channel)
+KIND_SATURATED = 3   # org = 1023, pred = 0 on a checkerboard, swapped elsewhere
+KIND_FLAT = 4        # constant org, constant pred
+
+
+def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, first: int = 0):
+    """Returns (org, pred) int16 arrays of shape [n, size, size] (dense, stride == size).
+
+    Patch i is a function of (input_seed, first + i) only, so a rank can generate its own shard.
+    """
+    org = np.empty((n, size, size), dtype=np.int16)
+    pred = np.empty((n, size, size), dtype=np.int16)
+    px = size * size
+    for i in range(n):
+        idx = first + i
+        tag = f"patch{idx}"
+        if kind == KIND_TEXTURE:
+            nb = max(size // 16, 1)
+            base = randint(input_seed, tag + "/base", nb * nb, 64, 959).reshape(nb, nb)
+            base = np.kron(base, np.ones((size // nb, size // nb), dtype=np.int64))
+            tex = randint(input_seed, tag + "/tex", px, -48, 48).reshape(size, size)
+            o = np.clip(base + tex, 0, 1023)
+            noise = randint(input_seed, tag + "/noise", px, -40, 40).reshape(size, size)
+            p = np.clip(o + noise, 0, 1023)
+        elif kind == KIND_UNIFORM:
+            o = randint(input_seed, tag + "/o", px, 0, 1023).reshape(size, size)
+            p = randint(input_seed, tag + "/p", px, 0, 1023).reshape(size, size)
+        elif kind == KIND_ZERO_RESI:
+            o = randint(input_seed, tag + "/o", px, 0, 1023).reshape(size, size)
+            p = o.copy()
+        elif kind == KIND_SATURATED:
+            yy, xx = np.mgrid[0:size, 0:size]
+            chk = ((yy // 4 + xx // 4) & 1).astype(np.int64)
+            o = chk * 1023
+            p = (1 - chk) * 1023
+        elif kind == KIND_FLAT:
+            o = np.full((size, size), int(randint(input_seed, tag + "/o", 1, 0, 1023)[0]), dtype=np.int64)
+            p = np.full((size, size), int(randint(input_seed, tag + "/p", 1, 0, 1023)[0]), dtype=np.int64)
+        else:
+            raise ValueError(kind)
+        org[i] = o.astype(np.int16)
+        pred[i] = p.astype(np.int16)
+    return org, pred
+
+
+def make_scalars(n: int, input_seed: int, first: int = 0):
+    """poc uniform [0,600], qp uniform [17,47] as int32 arrays of length n."""
+    poc = randint(input_seed, "poc", n, 0, 600, offset=first).astype(np.int32)
+    qp = randint(input_seed, "qp", n, 17, 47, offset=first).astype(np.int32)
+    return poc, qp
