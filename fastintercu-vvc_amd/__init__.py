@@ -3,6 +3,7 @@
 The directory name carries a hyphen (it mirrors the reference repo's name), so import it
 through `mltcnn_pkg.load()` at the repo root, which registers it as `fastintercu_vvc_amd`.
 """
-from . import synth, weights  # noqa: F401
+from . import build, capi, synth, weights  # noqa: F401
+from .capi import MltCnn, MltError  # noqa: F401
 
-__all__ = ["synth", "weights"]
+__all__ = ["build", "capi", "synth", "weights", "MltCnn", "MltError"]

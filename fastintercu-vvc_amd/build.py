@@ -1,0 +1,39 @@
+"""Build recipe for the HIP extension (in-tree, gfx950 only): csrc/*.hip + *.cpp -> libmltcnn_hip.so."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmltcnn_hip.so")
+SOURCES = ["mlt_kernels.hip", "mlt_model.cpp", "mlt_api.cpp"]
+HEADERS = ["mlt_kernels.h", "mlt_model.h", os.path.join("..", "..", "include", "mltcnn.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compiles without a GPU (hipcc only needs the gfx950 target)."""
+    if force or stale():
+        cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB

@@ -1,0 +1,509 @@
+// mlt_api.cpp -- C ABI (include/mltcnn.h) and host runtime of the MI355X MLT-CNN split predictor.
+//
+// Replaces the inline block EncCu.cpp:799-930 of the reference encoder: what was
+//   xMalloc + copy loops (:810-830), cv::absdiff/convertTo/clip (:832-867), from_blob/cat/.to(kCUDA) (:869-887),
+//   torch::jit::load PER CALL (:894-900), forward (:909), .cpu()/argmax (:920-921)
+// becomes: one init (weights folded, packed, resident in HBM), then per call a strided H2D copy of the two
+// Pel planes, a fixed chain of HIP kernel launches on one stream, and a few bytes D2H.
+// There is NO CPU fallback: without a usable HIP device mlt_init fails with MLT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mltcnn.h"
+#include "mlt_kernels.h"
+#include "mlt_model.h"
+
+namespace {
+
+std::string g_init_error;
+std::mutex g_mutex;
+
+int size_index(int size) {
+  switch (size) {
+    case 128: return 0;
+    case 64: return 1;
+    case 32: return 2;
+    case 16: return 3;
+    default: return -1;
+  }
+}
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct SizeState {
+  bool enabled = false, loaded = false;
+  int size = 0, head_index = 0;
+  mlt::Model model;
+};
+
+struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+
+}  // namespace
+
+struct mlt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  SizeState sz[4];
+  int max_batch = 4096, chunk = 1024;
+  char *ws = nullptr;
+  size_t ws_bytes = 0;
+  // staging for the host-pointer entry points
+  char *stage = nullptr;
+  size_t stage_bytes = 0;
+  std::string err;
+  bool profile = false;
+  std::map<std::string, ProfAcc> prof;
+  std::vector<std::string> prof_order;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                             \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                 \
+      return MLT_ERR_HIP;                                                                              \
+    }                                                                                                  \
+  } while (0)
+
+int upload_model(mlt_ctx *ctx, mlt::Model &m) {
+  auto up = [&](mlt::PackedConv &pc) -> int {
+    HIP_TRY(ctx, hipMalloc(&pc.d_w, pc.w.size() * 2));
+    HIP_TRY(ctx, hipMemcpy(pc.d_w, pc.w.data(), pc.w.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void **)&pc.d_bias, pc.bias.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(pc.d_bias, pc.bias.data(), pc.bias.size() * 4, hipMemcpyHostToDevice));
+    return MLT_OK;
+  };
+  int rc;
+  if ((rc = up(m.stem))) return rc;
+  for (int s = 0; s < m.n_stages; ++s)
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = up(m.blocks[s][b].conv1))) return rc;
+      if ((rc = up(m.blocks[s][b].conv2))) return rc;
+      if (m.blocks[s][b].has_sc && (rc = up(m.blocks[s][b].sc))) return rc;
+    }
+  for (int h = 0; h < m.n_heads; ++h) {
+    mlt::Head &H = m.heads[h];
+    HIP_TRY(ctx, hipMalloc((void **)&H.d_w, H.w.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(H.d_w, H.w.data(), H.w.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void **)&H.d_b, H.b.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(H.d_b, H.b.data(), H.b.size() * 4, hipMemcpyHostToDevice));
+  }
+  m.on_device = true;
+  return MLT_OK;
+}
+
+void free_model(mlt::Model &m) {
+  auto fr = [](mlt::PackedConv &pc) { if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_bias) (void)hipFree(pc.d_bias); pc.d_w = nullptr; pc.d_bias = nullptr; };
+  fr(m.stem);
+  for (int s = 0; s < 5; ++s)
+    for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); fr(m.blocks[s][b].sc); }
+  for (int h = 0; h < 4; ++h) { if (m.heads[h].d_w) (void)hipFree(m.heads[h].d_w); if (m.heads[h].d_b) (void)hipFree(m.heads[h].d_b); m.heads[h].d_w = m.heads[h].d_b = nullptr; }
+  m.on_device = false;
+}
+
+// activation workspace (bytes per CU) for size S: stem + 4 scratch maps of stage-0 size + one output per stage
+size_t ws_per_cu(const mlt::Model &m, int S) {
+  size_t b = (size_t)S * S * 32 * 2;
+  const int h0 = S / 2 > 0 ? S / 2 : 1;
+  b += 4 * (size_t)h0 * h0 * 32 * 2;
+  int h = S;
+  for (int s = 0; s < m.n_stages; ++s) { h = h / 2 > 0 ? h / 2 : 1; b += (size_t)h * h * m.planes[s] * 2; }
+  return b + 4096;
+}
+
+int ensure_ws(mlt_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return MLT_OK;
+  if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  HIP_TRY(ctx, hipMalloc((void **)&ctx->ws, bytes));
+  ctx->ws_bytes = bytes;
+  return MLT_OK;
+}
+
+// MLT_DEBUG_DUMP_DIR=<dir>: after every kernel, synchronise and write the output tensor to <dir>/<seq>_<name>.bin
+// (bring-up aid only; never set in production or in timed runs).
+int debug_dump(mlt_ctx *ctx, const char *name, const void *dptr, size_t bytes) {
+  static const char *dir = std::getenv("MLT_DEBUG_DUMP_DIR");
+  static int seq = 0;
+  if (!dir) return MLT_OK;
+  std::vector<char> host(bytes);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(host.data(), dptr, bytes, hipMemcpyDeviceToHost));
+  char path[1200];
+  std::snprintf(path, sizeof path, "%s/%02d_%s.bin", dir, seq++, name);
+  if (FILE *f = std::fopen(path, "wb")) { std::fwrite(host.data(), 1, bytes, f); std::fclose(f); }
+  return MLT_OK;
+}
+
+struct Launch {
+  mlt_ctx *ctx;
+  int prof_begin(const std::string &name, double flops, double bytes, hipEvent_t &e0, hipEvent_t &e1) {
+    if (!ctx->profile) return MLT_OK;
+    auto it = ctx->prof.find(name);
+    if (it == ctx->prof.end()) { ctx->prof_order.push_back(name); it = ctx->prof.emplace(name, ProfAcc()).first; }
+    it->second.launches++; it->second.flops += flops; it->second.bytes += bytes;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    it->second.ev.emplace_back(e0, e1);
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    return MLT_OK;
+  }
+  int prof_end(hipEvent_t e1) {
+    if (!ctx->profile) return MLT_OK;
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    return MLT_OK;
+  }
+};
+
+int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const void *x, void *y, const void *res, bool relu, int *hout_out) {
+  const int hout = hin / pc.stride > 0 ? hin / pc.stride : 1;
+  *hout_out = hout;
+  ConvArgs a{};
+  a.x = x; a.y = y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = res; a.n = n; a.relu = relu ? 1 : 0;
+  a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
+  const int MT = mlt_conv_tile_pixels(pc.cin, pc.cout, pc.stride, pc.taps);
+  int tw = hout < 32 ? hout : 32;
+  int th = MT / tw < hout ? MT / tw : hout;
+  int spw = MT / (tw * th);
+  const int halo = pc.taps == 9 ? 3 : 1;
+  const int PS = pc.kc * 2 + 16;
+  const int ph = (th - 1) * pc.stride + halo, pw = (tw - 1) * pc.stride + halo;
+  const int half = pc.stride == 2 ? (pw + 1) / 2 : 0;
+  const int rp = pc.stride == 2 ? 2 * half : pw;
+  while (spw > 1 && (size_t)spw * ph * rp * PS > 64 * 1024) spw /= 2;
+  a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
+  a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
+  a.pw_magic = (0x100000000ull + pw - 1) / pw;
+  a.ph_magic = (0x100000000ull + ph - 1) / ph;
+  a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
+  const int grid_x = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
+  char name[48];
+  std::snprintf(name, sizeof name, "conv%dx%d_s%d_%dto%d_h%d", pc.taps == 9 ? 3 : 1, pc.taps == 9 ? 3 : 1, pc.stride, pc.cin, pc.cout, hout);
+  const double px = (double)n * hout * hout;
+  const double flops = 2.0 * px * pc.cout * pc.cin * pc.taps;
+  const double bytes = (double)n * hin * hin * pc.cin * 2 + px * pc.cout * 2 * (res ? 2 : 1) + (double)pc.w.size() * 2;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin(name, flops, bytes, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.taps, a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  return debug_dump(ctx, name, y, (size_t)px * pc.cout * 2);
+}
+
+// One chunk of n CUs through the whole network, everything on ctx->stream.
+int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs,
+                long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
+  mlt::Model &m = st.model;
+  const int S = st.size;
+  int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
+  if (rc) return rc;
+  // carve the workspace
+  char *p = ctx->ws;
+  auto carve = [&](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return (void *)r; };
+  void *stem = carve((size_t)n * S * S * 32 * 2);
+  const int h0 = S / 2 > 0 ? S / 2 : 1;
+  void *pool[4];
+  for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2);
+  void *outs[5];
+  {
+    int h = S;
+    for (int s = 0; s < m.n_stages; ++s) { h = h / 2 > 0 ? h / 2 : 1; outs[s] = carve((size_t)n * h * h * m.planes[s] * 2); }
+  }
+  Launch L{ctx};
+  {  // stem (arch:277-278) fused with the preprocessing of EncCu.cpp:810-867
+    StemArgs a{};
+    a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
+    a.w = m.stem.d_w; a.y = stem; a.s_l = ilog2(S);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    char name[48];
+    std::snprintf(name, sizeof name, "stem_h%d", S);
+    if ((rc = L.prof_begin(name, 2.0 * n * S * S * 32 * 18, (double)n * S * S * (4 + 64), e0, e1))) return rc;
+    HIP_TRY(ctx, mlt_launch_stem(a, n, ctx->stream));
+    if ((rc = L.prof_end(e1))) return rc;
+    if ((rc = debug_dump(ctx, name, stem, (size_t)n * S * S * 32 * 2))) return rc;
+  }
+  const void *cur = stem;
+  int h = S;
+  HeadArgs ha{};
+  for (int s = 0; s < m.n_stages; ++s) {
+    int hout = h;
+    // block 0 (stride 2, projection shortcut): t = relu(bn1(conv1 x)); sc = bn(conv1x1 x); b0 = relu(bn2(conv2 t) + sc)
+    mlt::Block &B0 = m.blocks[s][0];
+    if ((rc = run_conv(ctx, B0.conv1, n, h, cur, pool[0], nullptr, true, &hout))) return rc;
+    if ((rc = run_conv(ctx, B0.sc, n, h, cur, pool[1], nullptr, false, &hout))) return rc;
+    int h2;
+    if ((rc = run_conv(ctx, B0.conv2, n, hout, pool[0], pool[2], pool[1], true, &h2))) return rc;
+    // block 1 (identity shortcut)
+    mlt::Block &B1 = m.blocks[s][1];
+    if ((rc = run_conv(ctx, B1.conv1, n, hout, pool[2], pool[3], nullptr, true, &h2))) return rc;
+    if ((rc = run_conv(ctx, B1.conv2, n, hout, pool[3], outs[s], pool[2], true, &h2))) return rc;
+    cur = outs[s];
+    h = hout;
+    if (s >= 1) {
+      const int hd = s - 1;
+      ha.feat[hd] = outs[s]; ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
+      ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
+    }
+  }
+  ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
+  {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((rc = L.prof_begin("gap_heads", 0.0, 0.0, e0, e1))) return rc;
+    HIP_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
+    if ((rc = L.prof_end(e1))) return rc;
+  }
+  return MLT_OK;
+}
+
+int check_size(mlt_ctx *ctx, int size, SizeState **out) {
+  const int si = size_index(size);
+  if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
+  SizeState &st = ctx->sz[si];
+  if (!st.enabled || !st.loaded) { ctx->err = "CU size not enabled or weights not loaded"; return MLT_ERR_SIZE_DISABLED; }
+  *out = &st;
+  return MLT_OK;
+}
+
+int ensure_stage(mlt_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->stage_bytes) return MLT_OK;
+  if (ctx->stage) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+  HIP_TRY(ctx, hipMalloc((void **)&ctx->stage, bytes));
+  ctx->stage_bytes = bytes;
+  return MLT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int mlt_abi_version(void) { return MLT_ABI_VERSION; }
+
+int mlt_num_logits(int size) { return size == 128 ? 9 : (size == 64 || size == 32 || size == 16) ? 15 : 0; }
+
+const char *mlt_last_error(const mlt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
+  if (!ctx || !blob) return MLT_ERR_ARG;
+  const int si = size_index(size);
+  if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
+  SizeState &st = ctx->sz[si];
+  if (!st.enabled) { ctx->err = "CU size not enabled in size_mask"; return MLT_ERR_SIZE_DISABLED; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  mlt::Model m;
+  std::string err;
+  if (!mlt::build_model(blob, bytes, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
+  if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); st.loaded = false; }
+  st.model = std::move(m);
+  int rc = upload_model(ctx, st.model);
+  if (rc) return rc;
+  if (st.head_index < 0 || st.head_index >= st.model.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
+  st.loaded = true;
+  return MLT_OK;
+}
+
+int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!cfg || !out || cfg->struct_size != sizeof(mlt_config)) { g_init_error = "bad mlt_config"; return MLT_ERR_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    g_init_error = "no usable HIP device (this library has no CPU fallback)";
+    return MLT_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess) { g_init_error = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  mlt_ctx *ctx = new (std::nothrow) mlt_ctx();
+  if (!ctx) return MLT_ERR_NOMEM;
+  ctx->device = cfg->device;
+  ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
+  if (const char *e = std::getenv("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_init_error = "hipStreamCreate failed"; delete ctx; return MLT_ERR_HIP; }
+  ctx->own_stream = true;
+  const uint32_t mask = cfg->size_mask ? cfg->size_mask : MLT_SIZE_128;  // reference gate: 128 only (EncCu.cpp:754)
+  static const int sizes[4] = {128, 64, 32, 16};
+  for (int i = 0; i < 4; ++i) {
+    SizeState &st = ctx->sz[i];
+    st.size = sizes[i];
+    st.enabled = (mask >> i) & 1u;
+    st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
+    if (st.enabled && cfg->weights_dir) {
+      char path[1024];
+      std::snprintf(path, sizeof path, "%s/MLTORPQ_splitMode_%d.mltw", cfg->weights_dir, sizes[i]);  // cf. EncCu.cpp:899
+      FILE *f = std::fopen(path, "rb");
+      if (!f) { g_init_error = std::string("cannot open ") + path; mlt_shutdown(ctx); return MLT_ERR_WEIGHTS; }
+      std::fseek(f, 0, SEEK_END);
+      long len = std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      std::vector<char> buf(len > 0 ? len : 0);
+      const size_t got = len > 0 ? std::fread(buf.data(), 1, len, f) : 0;
+      std::fclose(f);
+      int rc = got == (size_t)len ? mlt_load_weights(ctx, sizes[i], buf.data(), buf.size()) : MLT_ERR_WEIGHTS;
+      if (rc) { g_init_error = ctx->err.empty() ? std::string("short read: ") + path : ctx->err; mlt_shutdown(ctx); return rc; }
+    }
+  }
+  *out = ctx;
+  return MLT_OK;
+}
+
+void mlt_shutdown(mlt_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->prof)
+    for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (int i = 0; i < 4; ++i) free_model(ctx->sz[i].model);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int mlt_set_stream(mlt_ctx *ctx, void *hip_stream) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return MLT_OK;
+}
+
+int mlt_synchronize(mlt_ctx *ctx) {
+  if (!ctx) return MLT_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MLT_OK;
+}
+
+int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, const void *d_pred, const void *d_poc, const void *d_qp,
+                             void *d_split_mode, void *d_logits) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (n < 0 || !d_split_mode || (n > 0 && (!d_org || !d_pred || !d_poc || !d_qp))) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (n == 0) return MLT_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  const int nl = st->model.n_logits;
+  const long cs = (long)size * size;
+  for (int i0 = 0; i0 < n; i0 += ctx->chunk) {
+    const int c = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+    rc = run_network(ctx, *st, c, (const int16_t *)d_org + (size_t)i0 * cs, size, cs, (const int16_t *)d_pred + (size_t)i0 * cs, size, cs,
+                     (const int32_t *)d_poc + i0, (const int32_t *)d_qp + i0, (int32_t *)d_split_mode + i0,
+                     d_logits ? (float *)d_logits + (size_t)i0 * nl : nullptr);
+    if (rc) return rc;
+  }
+  return MLT_OK;
+}
+
+int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp,
+                      int32_t *split_mode, float *logits) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (n < 0 || !split_mode || (n > 0 && (!org || !pred || !poc || !qp))) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (n == 0) return MLT_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  const int nl = st->model.n_logits;
+  const size_t cs = (size_t)size * size;
+  const int cap = n < ctx->chunk ? n : ctx->chunk;
+  const size_t plane = (cs * 2 * cap + 255) / 256 * 256;
+  const size_t small = ((size_t)cap * 4 + 255) / 256 * 256;
+  const size_t lgb = ((size_t)cap * nl * 4 + 255) / 256 * 256;
+  if ((rc = ensure_stage(ctx, 2 * plane + 3 * small + lgb))) return rc;
+  int16_t *d_org = (int16_t *)ctx->stage, *d_pred = (int16_t *)(ctx->stage + plane);
+  int32_t *d_poc = (int32_t *)(ctx->stage + 2 * plane), *d_qp = (int32_t *)(ctx->stage + 2 * plane + small);
+  int32_t *d_split = (int32_t *)(ctx->stage + 2 * plane + 2 * small);
+  float *d_lg = (float *)(ctx->stage + 2 * plane + 3 * small);
+  for (int i0 = 0; i0 < n; i0 += cap) {
+    const int c = n - i0 < cap ? n - i0 : cap;
+    HIP_TRY(ctx, hipMemcpyAsync(d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = run_network(ctx, *st, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(split_mode + i0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)i0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MLT_OK;
+}
+
+int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride, int size, int32_t poc, int32_t qp,
+                int32_t *split_mode, float *logits_opt) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (!org || !pred || !split_mode || org_stride < size || pred_stride < size) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  const int nl = st->model.n_logits;
+  const size_t cs = (size_t)size * size;
+  const size_t plane = (cs * 2 + 255) / 256 * 256;
+  if ((rc = ensure_stage(ctx, 2 * plane + 1024))) return rc;
+  int16_t *d_org = (int16_t *)ctx->stage, *d_pred = (int16_t *)(ctx->stage + plane);
+  int32_t *d_sc = (int32_t *)(ctx->stage + 2 * plane);  // [poc, qp, split, pad, logits...]
+  // the gather of EncCu.cpp:810-830 as two strided copies (rows of `size` Pels out of a `stride`-Pel pitch)
+  HIP_TRY(ctx, hipMemcpy2DAsync(d_org, (size_t)size * 2, org, (size_t)org_stride * 2, (size_t)size * 2, size, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpy2DAsync(d_pred, (size_t)size * 2, pred, (size_t)pred_stride * 2, (size_t)size * 2, size, hipMemcpyHostToDevice, ctx->stream));
+  const int32_t sc[2] = {poc, qp};
+  HIP_TRY(ctx, hipMemcpyAsync(d_sc, sc, 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+  int32_t back[4 + MLT_MAX_LOGITS];
+  HIP_TRY(ctx, hipMemcpyAsync(back, d_sc, (size_t)(4 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *split_mode = back[2];
+  if (logits_opt) std::memcpy(logits_opt, back + 4, (size_t)nl * 4);
+  return MLT_OK;
+}
+
+void *mlt_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void mlt_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+int mlt_profile_enable(mlt_ctx *ctx, int on) {
+  if (!ctx) return MLT_ERR_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &kv : ctx->prof)
+    for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  ctx->prof.clear();
+  ctx->prof_order.clear();
+  ctx->profile = on != 0;
+  return MLT_OK;
+}
+
+int mlt_profile_read(mlt_ctx *ctx, mlt_kernel_time *out, int cap) {
+  if (!ctx) return -1;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+  int i = 0;
+  for (const std::string &name : ctx->prof_order) {
+    ProfAcc &acc = ctx->prof[name];
+    if (out && i < cap) {
+      mlt_kernel_time &t = out[i];
+      std::memset(&t, 0, sizeof t);
+      std::snprintf(t.name, sizeof t.name, "%s", name.c_str());
+      t.launches = acc.launches; t.flops = acc.flops; t.bytes = acc.bytes;
+      float total = 0.f;
+      for (auto &ev : acc.ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) total += ms; }
+      t.total_ms = total;
+    }
+    ++i;
+  }
+  return i;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,208 @@
+// mlt_model.cpp -- host side of weight handling: MLTW blob -> BN-folded, fp16, MFMA-fragment-packed
+// tensors.  Replaces what torch::jit::load did per call in the reference (EncCu.cpp:894-900); runs once.
+//
+// BN folding (eval mode, eps 1e-5; arch:39,42,49 / SURVEY.md A.2):  w' = w * gamma/sqrt(var+eps),
+// b' = beta - mean * gamma/sqrt(var+eps), in double, before the cast to fp16.
+//
+// fp16 rounding: "tap-diffused" -- within each (cout, cin) pair the 9 taps are rounded in order and each
+// target is corrected by the accumulated rounding error of the previous taps, so sum_taps(w_fp16) tracks
+// sum_taps(w) to half an ulp.  Activations are spatially smooth, so the coherent part of the weight
+// rounding error (the part global average pooling cannot average away) cancels.  Every value is still
+// within one fp16 ulp of the folded fp32 weight.
+#include "mlt_model.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace mlt {
+
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7FFFFFFFu;
+  if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x200u : 0));
+  if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to inf
+  if (x < 0x38800000u) {                                    // subnormal half or zero
+    if (x < 0x33000000u) return (uint16_t)sign;
+    const int e = (int)(x >> 23);
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    const int shift = 126 - e;  // 14..24
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((x - 0x38000000u) >> 13);
+  const uint32_t rem = x & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+  return (uint16_t)(sign | r);
+}
+
+float f16_to_f32(uint16_t hbits) {
+  const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+  uint32_t e = (hbits >> 10) & 0x1F, m = hbits & 0x3FF, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      int sh = 0;
+      while (!(m & 0x400)) { m <<= 1; ++sh; }
+      x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3FF) << 13);
+    }
+  } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+  else x = sign | ((e + 112) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+#pragma pack(push, 1)
+struct BlobHead { char magic[4]; uint32_t version, arch, n; };
+struct BlobEntry { char name[64]; uint32_t ndim, dims[4]; uint64_t off, numel; };
+#pragma pack(pop)
+
+struct BlobView {
+  const BlobEntry *e = nullptr;
+  uint32_t n = 0;
+  const float *data = nullptr;
+  size_t nfloats = 0;
+  const float *find(const char *name, uint64_t numel, std::string &err) const {
+    for (uint32_t i = 0; i < n; ++i)
+      if (std::strncmp(e[i].name, name, 64) == 0) {
+        if (e[i].numel != numel || e[i].off + e[i].numel > nfloats) { err = std::string("tensor ") + name + ": bad size"; return nullptr; }
+        return data + e[i].off;
+      }
+    err = std::string("tensor ") + name + " missing from blob";
+    return nullptr;
+  }
+};
+
+static void fold_scale(const BlobView &b, const std::string &prefix, int c, std::vector<double> &scale, std::vector<float> &bias, std::string &err) {
+  const float *g = b.find((prefix + ".weight").c_str(), c, err);
+  const float *be = b.find((prefix + ".bias").c_str(), c, err);
+  const float *mu = b.find((prefix + ".running_mean").c_str(), c, err);
+  const float *var = b.find((prefix + ".running_var").c_str(), c, err);
+  scale.assign(c, 1.0);
+  bias.assign(c, 0.f);
+  if (!g || !be || !mu || !var) return;
+  for (int i = 0; i < c; ++i) {
+    const double s = (double)g[i] / std::sqrt((double)var[i] + 1e-5);
+    scale[i] = s;
+    bias[i] = (float)((double)be[i] - (double)mu[i] * s);
+  }
+}
+
+// w: torch layout [cout][cin][taps]; scale: per-cout multiplier.  Output: fragment-packed fp16 (see header).
+static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> &scale) {
+  const int cin = pc.cin, cout = pc.cout, taps = pc.taps;
+  const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
+  pc.w.assign((size_t)cout * cin * taps, 0);
+  for (int co = 0; co < cout; ++co) {
+    const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
+    for (int ci = 0; ci < cin; ++ci) {
+      const int chunk = ci / KC, kk = ci % KC, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
+      double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of this (co, ci)
+      for (int t = 0; t < taps; ++t) {
+        const double exact = (double)w[((size_t)co * cin + ci) * taps + t] * scale[co];
+        const uint16_t q = f32_to_f16((float)(exact - err));
+        err += (double)f16_to_f32(q) - exact;
+        const size_t idx = ((((size_t)(ctile * NCHUNK + chunk) * taps + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j;
+        pc.w[idx] = q;
+      }
+    }
+  }
+}
+
+// Stem: K index k = 2*tap + channel (18 used of 32), cout = 32; the 1/1023 input scale (EncCu.cpp:836,838)
+// is folded in because the kernel feeds exact integer fp16 inputs.
+static void pack_stem(PackedConv &pc, const float *w) {
+  pc.w.assign(2 * 64 * 8, 0);
+  for (int co = 0; co < 32; ++co)
+    for (int c = 0; c < 2; ++c) {
+      double err = 0.0;
+      for (int t = 0; t < 9; ++t) {
+        const double exact = (double)w[((size_t)co * 2 + c) * 9 + t] * (double)(float)(1.0 / 1023);
+        const uint16_t q = f32_to_f16((float)(exact - err));
+        err += (double)f16_to_f32(q) - exact;
+        const int k = 2 * t + c, ks = k / 16, hh = (k % 16) / 8, j = k % 8;
+        pc.w[((size_t)ks * 64 + hh * 32 + co) * 8 + j] = q;
+      }
+    }
+}
+
+bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
+  if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
+  const BlobHead *h = (const BlobHead *)blob;
+  if (std::memcmp(h->magic, "MLTW", 4) != 0 || h->version != 1 || h->arch > 1) { err = "not an MLTW v1 blob"; return false; }
+  const size_t hdr = sizeof(BlobHead) + (size_t)h->n * sizeof(BlobEntry);
+  if (bytes < hdr) { err = "truncated blob header"; return false; }
+  std::vector<float> data((bytes - hdr) / 4);  // aligned copy
+  std::memcpy(data.data(), (const char *)blob + hdr, data.size() * 4);
+  BlobView b;
+  b.e = (const BlobEntry *)((const char *)blob + sizeof(BlobHead));
+  b.n = h->n;
+  b.data = data.data();
+  b.nfloats = data.size();
+
+  m = Model();
+  m.arch = (int)h->arch;
+  static const int planes_ctu[4] = {32, 64, 128, 256}, planes_cu[5] = {32, 64, 96, 128, 256};  // arch:243-256 / cu arch:63-79
+  static const int cls_ctu[3] = {2, 3, 4}, cls_cu[4] = {2, 3, 4, 6};
+  m.n_stages = m.arch == 0 ? 4 : 5;
+  m.n_heads = m.n_stages - 1;
+
+  err.clear();
+  {
+    const float *w = b.find("conv1.weight", 32 * 2 * 9, err);
+    if (!w) return false;
+    m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 9; m.stem.stride = 1; m.stem.kc = 32; m.stem.ct = 32;
+    pack_stem(m.stem, w);
+    m.stem.bias.assign(32, 0.f);
+  }
+  int cin = 32;
+  char nm[96];
+  for (int s = 0; s < m.n_stages; ++s) {
+    const int c = m.arch == 0 ? planes_ctu[s] : planes_cu[s];
+    m.planes[s] = c;
+    for (int bi = 0; bi < 2; ++bi) {
+      Block &B = m.blocks[s][bi];
+      const int bin = bi == 0 ? cin : c, st = bi == 0 ? 2 : 1;  // _make_layer strides [2,1] (arch:265-271)
+      auto make = [&](PackedConv &pc, const char *wname, const char *bnname, int ci, int taps, int stride) -> bool {
+        pc.cin = ci; pc.cout = c; pc.taps = taps; pc.stride = stride;
+        pc.kc = (ci % 64 == 0) ? 64 : 32;
+        pc.ct = c >= 128 ? 128 : c;
+        std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, wname);
+        const float *w = b.find(nm, (uint64_t)c * ci * taps, err);
+        if (!w) return false;
+        std::vector<double> scale;
+        std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, bnname);
+        fold_scale(b, nm, c, scale, pc.bias, err);
+        if (!err.empty()) return false;
+        pack_conv(pc, w, scale);
+        return true;
+      };
+      if (!make(B.conv1, "conv1.weight", "bn1", bin, 9, st)) return false;
+      if (!make(B.conv2, "conv2.weight", "bn2", c, 9, 1)) return false;
+      B.has_sc = (st != 1 || bin != c);  // arch:44-45
+      if (B.has_sc && !make(B.sc, "shortcut.0.weight", "shortcut.1", bin, 1, st)) return false;
+    }
+    cin = c;
+    if (s >= 1) {
+      Head &H = m.heads[s - 1];
+      H.classes = m.arch == 0 ? cls_ctu[s - 1] : cls_cu[s - 1];
+      H.c = c;
+      std::snprintf(nm, sizeof nm, "branch%d.weight", s);
+      const float *w = b.find(nm, (uint64_t)H.classes * (c + 2), err);
+      std::snprintf(nm, sizeof nm, "branch%d.bias", s);
+      const float *bb = b.find(nm, H.classes, err);
+      if (!w || !bb) return false;
+      H.w.assign(w, w + (size_t)H.classes * (c + 2));
+      H.b.assign(bb, bb + H.classes);
+      m.n_logits += H.classes;
+    }
+  }
+  return true;
+}
+
+}  // namespace mlt

@@ -1,0 +1,47 @@
+// mlt_model.h -- host-side model description (folded + packed weights).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace mlt {
+
+// fp16 weights in MFMA A-fragment order:
+//   [cout tile (cout/ct)][cin chunk (cin/kc)][tap][k-step (kc/16)][32-channel block (ct/32)][lane 64][8 halves]
+// lane l = 32*hh + r holds W'[cout = tile*ct + blk*32 + r][cin = chunk*kc + 16*ks + 8*hh + j][tap], j = 0..7.
+struct PackedConv {
+  int cin = 0, cout = 0, taps = 0, stride = 1;
+  int kc = 0, ct = 0;
+  std::vector<uint16_t> w;
+  std::vector<float> bias;  // folded BN bias (zeros for the stem)
+  void *d_w = nullptr;      // device copies
+  float *d_bias = nullptr;
+};
+
+struct Block {
+  PackedConv conv1, conv2, sc;
+  bool has_sc = false;
+};
+
+struct Head {
+  int classes = 0, c = 0;
+  std::vector<float> w, b;  // w [classes][c+2], columns [features..., poc, qp] (arch:284)
+  float *d_w = nullptr, *d_b = nullptr;
+};
+
+struct Model {
+  int arch = 0, n_stages = 0, n_heads = 0, n_logits = 0;
+  int planes[5] = {0, 0, 0, 0, 0};
+  PackedConv stem;
+  Block blocks[5][2];
+  Head heads[4];
+  bool on_device = false;
+};
+
+bool build_model(const void *blob, size_t bytes, Model &m, std::string &err);
+uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
+
+}  // namespace mlt

@@ -1,0 +1,119 @@
+/*
+ * mltcnn.h -- C ABI of the MI355X-native MLT-CNN inter-CU split predictor.
+ *
+ * Drop-in boundary for the inline CNN block of the reference encoder
+ *   /root/reference/vtm-mlt-cpp/source/Lib/EncoderLib/EncCu.cpp:799-930
+ * (the reference has no plugin API; this header IS the interface a maintainer binds, see
+ * INTEGRATION.md).  Plain C types only, no C++ exceptions cross it, no torch / OpenCV.
+ *
+ * Error contract (mirrors the reference's swallow-and-continue, EncCu.cpp:902-905,923-926):
+ * every call returns MLT_OK (0) or a non-zero code and NEVER aborts; on failure the caller
+ * leaves predictedSplitMode = -1, for which EncModeCtrl::setNewModeList is a no-op
+ * (EncModeCtrl.cpp:147-148) and the encoder falls back to exhaustive RDO.
+ */
+#ifndef MLTCNN_H
+#define MLTCNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLT_ABI_VERSION 1
+
+enum {
+  MLT_OK = 0,
+  MLT_ERR_ARG = 1,        /* bad pointer / size / batch */
+  MLT_ERR_NO_DEVICE = 2,  /* HIP device missing or unusable */
+  MLT_ERR_WEIGHTS = 3,    /* weight file / blob missing or malformed */
+  MLT_ERR_SIZE_DISABLED = 4, /* CU size not enabled in size_mask or no weights loaded for it */
+  MLT_ERR_HIP = 5,        /* a HIP runtime call failed (see mlt_last_error) */
+  MLT_ERR_NOMEM = 6
+};
+
+/* CU sizes the two reference models cover (EncCu.cpp:754 gate; only 128 is active upstream). */
+#define MLT_SIZE_128 0x1u
+#define MLT_SIZE_64 0x2u
+#define MLT_SIZE_32 0x4u
+#define MLT_SIZE_16 0x8u
+
+#define MLT_MAX_LOGITS 15 /* CU model: 2+3+4+6; CTU (128) model: 2+3+4 = 9 */
+
+typedef struct mlt_ctx mlt_ctx;
+
+typedef struct mlt_config {
+  uint32_t struct_size;   /* = sizeof(mlt_config) */
+  int32_t device;         /* HIP device ordinal (reference: at::kCUDA hard-coded, EncCu.cpp:804) */
+  const char *weights_dir;/* directory holding MLTORPQ_splitMode_<S>.mltw, the blob counterpart of the
+                             reference's hard-coded ".../torch_model/MLTORPQ_splitMode_<S>.pt"
+                             (EncCu.cpp:897-899).  NULL: load later with mlt_load_weights(). */
+  uint32_t size_mask;     /* MLT_SIZE_* bits to enable; 0 => MLT_SIZE_128 (reference default, :754) */
+  int32_t head_index[4];  /* decision head per size {128,64,32,16}; -1 => reference default:
+                             element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
+  int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
+  uint32_t flags;         /* reserved, 0 */
+} mlt_config;
+
+/* Create a context: selects the device, allocates workspaces, loads + folds + packs weights
+ * ONCE (the reference re-reads the .pt on every CU, EncCu.cpp:894-900).  Natural home:
+ * EncCu::init (EncCu.cpp:233-259).  Thread-compatible: one ctx per EncCu / encoder thread. */
+int mlt_init(const mlt_config *cfg, mlt_ctx **out);
+
+/* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
+ * blob arrives over RCCL broadcast instead of from weights_dir. */
+int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
+
+/* Replaces EncCu.cpp:806-921 for ONE CU: gathers size x size luma from the original and the
+ * prediction buffers (Pel = int16, element strides as AreaBuf exposes them, Buffer.h:94-105),
+ * absdiff, 1/1023 normalisation, network, argmax.  Synchronous.
+ *   split_mode  <- argmax of the decision head (first maximal index, like torch.argmax)
+ *   logits_opt  <- all head logits, lvl1..lvlN concatenated (mlt_num_logits(size) floats) or NULL */
+int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride,
+                int size, int32_t poc, int32_t qp, int32_t *split_mode, float *logits_opt);
+
+/* n CUs from HOST memory (pinned memory from mlt_alloc_pinned avoids a staging copy).
+ * org / pred: dense [n][size][size] int16.  Synchronous.  logits may be NULL. */
+int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred,
+                      const int32_t *poc, const int32_t *qp, int32_t *split_mode, float *logits);
+
+/* Same with every pointer in DEVICE memory; enqueues on the context's stream and returns
+ * without synchronising (call mlt_synchronize).  This is the HBM-resident path bench.py times. */
+int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, const void *d_pred,
+                             const void *d_poc, const void *d_qp, void *d_split_mode, void *d_logits);
+
+int mlt_synchronize(mlt_ctx *ctx);
+
+/* Use an existing hipStream_t (e.g. the caller's) instead of the context's own stream. */
+int mlt_set_stream(mlt_ctx *ctx, void *hip_stream);
+
+/* Pinned host staging buffers for mlt_predict_batch. */
+void *mlt_alloc_pinned(size_t bytes);
+void mlt_free_pinned(void *p);
+
+/* Number of logits returned per CU for `size` (9 for 128, 15 for 64/32/16, 0 if unsupported). */
+int mlt_num_logits(int size);
+
+/* Per-kernel device timing (HIP events on the context's stream): enable, run, then read.
+ * mlt_profile_read fills up to `cap` entries; returns the number of distinct kernels. */
+typedef struct mlt_kernel_time {
+  char name[48];
+  uint32_t launches;
+  float total_ms;
+  double flops;  /* algorithmic FLOPs summed over those launches */
+  double bytes;  /* algorithmic HBM bytes (inputs + outputs + weights once) summed over launches */
+} mlt_kernel_time;
+int mlt_profile_enable(mlt_ctx *ctx, int on);
+int mlt_profile_read(mlt_ctx *ctx, mlt_kernel_time *out, int cap);
+
+const char *mlt_last_error(const mlt_ctx *ctx); /* ctx may be NULL: last init error */
+int mlt_abi_version(void);
+
+/* Release everything (natural home: EncCu::destroy, EncCu.cpp:160-206). NULL is allowed. */
+void mlt_shutdown(mlt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLTCNN_H */

@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mltcnn.h declares; host logic that
+needs no GPU (argument checks, the no-device error path).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    pkg.build.build_lib()
+    return pkg.capi.load_library()
+
+
+def test_exports_match_header(pkg, lib):
+    header = open(os.path.join(ROOT, "include", "mltcnn.h")).read()
+    declared = set(re.findall(r"\b(mlt_[a-z_0-9]+)\s*\(", header))
+    declared -= {"mlt_config", "mlt_ctx", "mlt_kernel_time"}
+    assert declared == set(pkg.capi.EXPORTS), declared ^ set(pkg.capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mltcnn.h but not exported"
+
+
+def test_abi_version_and_logit_counts(lib):
+    assert lib.mlt_abi_version() == 1
+    assert [lib.mlt_num_logits(s) for s in (128, 64, 32, 16, 8)] == [9, 15, 15, 15, 0]
+
+
+def test_config_struct_layout(pkg):
+    # must match `struct mlt_config` in include/mltcnn.h (x86-64 SysV)
+    assert C.sizeof(pkg.capi.MltConfig) == 48
+    assert pkg.capi.MltConfig.weights_dir.offset == 8
+    assert pkg.capi.MltConfig.head_index.offset == 20
+    assert C.sizeof(pkg.capi.MltKernelTime) == 72
+
+
+def test_init_rejects_bad_config(pkg, lib):
+    h = C.c_void_p()
+    cfg = pkg.capi.MltConfig()
+    cfg.struct_size = 4
+    assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1  # MLT_ERR_ARG
+    assert lib.mlt_init(None, C.byref(h)) == 1
+
+
+def test_no_gpu_fails_loudly(pkg):
+    """No CPU fallback: without a HIP device the product path must refuse to run."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.MltError) as ei:
+        pkg.MltCnn(device=0, sizes=(128,))
+    assert ei.value.code == 2  # MLT_ERR_NO_DEVICE
+
+
+def test_null_ctx_calls_are_errors_not_crashes(lib):
+    assert lib.mlt_synchronize(None) == 1
+    assert lib.mlt_predict_batch_device(None, 1, 128, None, None, None, None, None, None) == 1
+    lib.mlt_shutdown(None)
+    lib.mlt_free_pinned(None)

@@ -1,0 +1,140 @@
+"""GPU (MI355X): the HIP path through the C ABI against (a) the committed reference fixtures and
+(b) the C oracle on seeded inputs.  Tolerance written here, from BASELINE.json's north_star:
+|dlogit| <= 1e-3 and identical split decision wherever the reference's own top-2 margin exceeds
+the tolerance."""
+import numpy as np
+import pytest
+
+from helpers import SIZES, decisive, head_slices, load_golden, materialise, variant_state_dict
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    pkg.build.build_lib()
+    return pkg
+
+
+def _ctx(pkg, size, blob, **kw):
+    return pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, **kw)
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_golden_fixtures(gpu, size):
+    pkg = gpu
+    golden = load_golden(size)
+    worst = {}
+    for case in golden["cases"]:
+        blob, org, pred, poc, qp, exp, exp_arg = materialise(pkg, golden, case)
+        m = _ctx(pkg, size, blob)
+        split, logits = m.predict_batch(org, pred, poc, qp)
+        err = float(np.abs(logits - exp).max())
+        worst[case["name"]] = err
+        assert err <= LOGIT_TOL, f"{size}/{case['name']}: |dlogit| {err:.3e}"
+        dec = 2 if size == 128 else 0
+        sl = head_slices([2, 3, 4] if size == 128 else [2, 3, 4, 6])[dec]
+        for i in range(case["n"]):
+            if decisive(exp[i], sl, 2 * LOGIT_TOL):
+                assert split[i] == exp_arg[i][dec], (case["name"], i)
+        m.close()
+    print(size, {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("size,n", [(128, 12), (64, 24), (32, 40), (16, 70)])
+def test_against_oracle_seeded(gpu, size, n):
+    """Ragged batch sizes (not multiples of the per-workgroup sample count) on purpose."""
+    from oracle import Oracle
+    pkg = gpu
+    arch = pkg.synth.arch_for_size(size)
+    blob = pkg.weights.synthetic_blob(arch, 21)
+    org, pred = pkg.synth.make_patches(size, n, 4321)
+    poc, qp = pkg.synth.make_scalars(n, 4321)
+    ref, ref_split = Oracle(blob).forward(org, pred, poc, qp, threads=8)
+    m = _ctx(pkg, size, blob)
+    split, logits = m.predict_batch(org, pred, poc, qp)
+    err = float(np.abs(logits - ref).max())
+    print(size, "max|dlogit| vs oracle", err)
+    assert err <= LOGIT_TOL
+    sl = head_slices(Oracle(blob).head_classes)[2 if size == 128 else 0]
+    for i in range(n):
+        if decisive(ref[i], sl, 2 * LOGIT_TOL):
+            assert split[i] == ref_split[i]
+    m.close()
+
+
+def test_single_cu_strided_call_site(gpu):
+    """mlt_predict with picture-buffer strides (EncCu.cpp:810-830) == batch path == oracle."""
+    from oracle import Oracle
+    pkg = gpu
+    size = 128
+    blob = pkg.weights.synthetic_blob(0, 10)
+    org, pred = pkg.synth.make_patches(size, 2, 99)
+    pic = np.full((2, size, 1920), -5, np.int16)
+    pic[:, :, 640:640 + size] = org
+    prd = np.full((2, size, size + 16), 7, np.int16)
+    prd[:, :, :size] = pred
+    m = _ctx(pkg, size, blob)
+    bs, bl = m.predict_batch(org, pred, [8, 16], [32, 37])
+    ref, _ = Oracle(blob).forward(org, pred, [8, 16], [32, 37])
+    for i in range(2):
+        s, l = m.predict(pic[i, :, 640:640 + size], prd[i, :, :size], [8, 16][i], [32, 37][i])
+        assert s == bs[i] and np.array_equal(l, bl[i])
+        assert np.abs(l - ref[i]).max() <= LOGIT_TOL
+    m.close()
+
+
+def test_first_max_tie_rule(gpu):
+    pkg = gpu
+    for size in (128, 32):
+        arch = pkg.synth.arch_for_size(size)
+        blob = pkg.weights.pack_blob(arch, variant_state_dict(pkg, arch, 10, "tie", size))
+        org, pred = pkg.synth.make_patches(size, 5, 77)
+        poc, qp = pkg.synth.make_scalars(5, 77)
+        m = _ctx(pkg, size, blob)
+        split, logits = m.predict_batch(org, pred, poc, qp)
+        sl = head_slices([2, 3, 4] if size == 128 else [2, 3, 4, 6])[2 if size == 128 else 0]
+        assert np.all(logits[:, sl][:, 0] == logits[:, sl][:, 1]), "identical rows must tie exactly"
+        assert np.all(split == 0), "torch.argmax returns the first maximal index"
+        m.close()
+
+
+def test_batch_split_invariance_and_determinism(gpu):
+    """Result of CU i must not depend on its batch neighbours or on the chunking; run-to-run identical."""
+    pkg = gpu
+    size = 64
+    blob = pkg.weights.synthetic_blob(1, 10)
+    org, pred = pkg.synth.make_patches(size, 37, 5)
+    poc, qp = pkg.synth.make_scalars(37, 5)
+    m = _ctx(pkg, size, blob)
+    s_all, l_all = m.predict_batch(org, pred, poc, qp)
+    s_again, l_again = m.predict_batch(org, pred, poc, qp)
+    assert np.array_equal(l_all, l_again) and np.array_equal(s_all, s_again)
+    for lo, hi in ((0, 1), (1, 9), (9, 37)):
+        s, l = m.predict_batch(org[lo:hi], pred[lo:hi], poc[lo:hi], qp[lo:hi])
+        assert np.array_equal(l, l_all[lo:hi]) and np.array_equal(s, s_all[lo:hi])
+    m.close()
+
+
+def test_head_index_option_and_errors(gpu):
+    pkg = gpu
+    blob = pkg.weights.synthetic_blob(1, 10)
+    org, pred = pkg.synth.make_patches(16, 6, 3)
+    poc, qp = pkg.synth.make_scalars(6, 3)
+    m0 = _ctx(pkg, 16, blob)
+    m3 = _ctx(pkg, 16, blob, head_index={16: 3})
+    s0, l0 = m0.predict_batch(org, pred, poc, qp)
+    s3, l3 = m3.predict_batch(org, pred, poc, qp)
+    assert np.array_equal(l0, l3)
+    assert np.array_equal(s0, np.argmax(l0[:, 0:2], axis=1)) and np.array_equal(s3, np.argmax(l0[:, 9:15], axis=1))
+    with pytest.raises(pkg.MltError) as ei:  # size not enabled -> caller keeps -1 -> full RDO
+        m0.predict_batch(*pkg.synth.make_patches(32, 1, 3), [0], [30])
+    assert ei.value.code == 4
+    with pytest.raises(pkg.MltError):
+        pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob})  # CU-arch blob for the 128 slot
+    with pytest.raises(pkg.MltError):
+        pkg.MltCnn(device=0, sizes=(128,), blobs={128: b"garbage"})
+    m0.close(); m3.close()
