@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- CU-inferences/s of the MI355X MLT-CNN split predictor (BASELINE.json metric).
+
+One "step" = one pass of the hot path (raw int16 org/pred planes + poc/qp already resident in HBM
+-> logits + split modes in HBM) over ONE batch of 4096 synthetic 128x128 CUs per GPU.
+N > 1: one process per GPU (torch.distributed.run), weights broadcast once over RCCL, the batch is
+sharded by rank with no hot-path collective (weak scaling: 4096 CUs per GPU).
+
+Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096
+SIZE = 128
+FLOP_PER_CU = 1_134_562_340          # 2 x MACs, conv + FC, S = 128
+LAYERWISE_BYTES_PER_CU = 8_061_854   # fp16 activations, every layer reads/writes HBM once
+COMPULSORY_BYTES_PER_CU = 65_580
+MFMA_PEAK_TFLOPS = 2500.0            # dense fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="CUs per GPU per step (BASELINE: 4096)")
+    ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import mltcnn_pkg
+    pkg = mltcnn_pkg.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pkg.build.build_lib()
+
+    size, B = args.size, args.batch
+    arch = pkg.synth.arch_for_size(size)
+    # ---- weights: rank 0 builds the blob, everyone else receives it over RCCL (xGMI) ----
+    if rank == 0:
+        blob = pkg.weights.synthetic_blob(arch, 10)
+    if world > 1:
+        ln = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(ln, 0)
+        t = torch.empty(int(ln.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        blob = bytes(t.cpu().numpy().tobytes())
+    m = pkg.MltCnn(device=local_rank, sizes=(size,), blobs={size: blob}, max_batch=B)
+
+    # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
+    org, pred = pkg.synth.make_patches_bulk(size, B, 0xC0FFEE, first=rank * B)
+    poc, qp = pkg.synth.make_scalars(B, 0xC0FFEE, first=rank * B)
+    d_org = torch.from_numpy(org).to(dev)
+    d_pred = torch.from_numpy(pred).to(dev)
+    d_poc = torch.from_numpy(poc).to(dev)
+    d_qp = torch.from_numpy(qp).to(dev)
+    nl = m.num_logits(size)
+    d_split = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    d_logits = torch.zeros((B, nl), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    m.set_stream(stream.cuda_stream)
+
+    def step():
+        m.predict_batch_device(B, size, d_org.data_ptr(), d_pred.data_ptr(), d_poc.data_ptr(), d_qp.data_ptr(),
+                               d_split.data_ptr(), d_logits.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    m.profile_enable(True)  # HIP events around every kernel launch, on the launch stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = m.profile_read()
+    m.profile_enable(False)
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- parity spot-check (outside the timed region): first CUs of this rank vs the CPU oracle ----
+    parity = None
+    if rank == 0:
+        import oracle
+        k = 8
+        ref, ref_split = oracle.Oracle(blob).forward(org[:k], pred[:k], poc[:k], qp[:k])
+        got = d_logits[:k].cpu().numpy()
+        parity = {"checked_cus": k, "max_abs_dlogit": float(np.abs(got - ref).max()),
+                  "split_identical": bool(np.array_equal(d_split[:k].cpu().numpy(), ref_split)), "tolerance": 1e-3}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    # ---- roofline of the dominant kernel (largest total device time) ----
+    dom = max(prof, key=lambda r: r["total_ms"]) if prof else None
+    roofline = None
+    kernels = []
+    tot_ms = sum(r["total_ms"] for r in prof) or 1.0
+    for r in prof:
+        avg_ms = r["total_ms"] / max(r["launches"], 1)
+        kernels.append({"name": r["name"], "launches": r["launches"], "avg_ms": round(avg_ms, 4),
+                        "share": round(r["total_ms"] / tot_ms, 4),
+                        "tflops": round(r["flops"] / max(r["total_ms"], 1e-9) / 1e9, 1),
+                        "algo_gbs": round(r["bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1)})
+    if dom:
+        avg_ms = dom["total_ms"] / dom["launches"]
+        ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                    "algo_flops_per_launch": dom["flops"] / dom["launches"],
+                    "algo_bytes_per_launch": dom["bytes"] / dom["launches"]}
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle
+        cores = os.cpu_count() or 1
+        sample = args.cpu_sample or min(B, 24 * cores)
+        orc = oracle.Oracle(blob)
+        orc.forward(org[:cores], pred[:cores], poc[:cores], qp[:cores], threads=cores)  # warm-up
+        c0 = time.perf_counter()
+        orc.forward(org[:sample], pred[:sample], poc[:sample], qp[:sample], threads=cores)
+        cs = time.perf_counter() - c0
+        cpu_baseline = {"value": round(sample / cs, 2), "unit": "CU-inferences/s", "cores": cores, "kind": "port",
+                        "sample": f"first {sample} CUs of the same batch, fp32 C oracle (oracle/mlt_oracle.c), OpenMP over CUs, {cs:.1f} s"}
+
+    out = {
+        "metric": "CU-inferences/sec (batch 4096, 128x128)", "value": round(value, 1), "unit": "CU-inferences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
+                               "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
+                   "batch_per_gpu": B, "cu_size": size, "weights": "synthetic seed 10 (no trained checkpoint is distributed)",
+                   "parallelism": f"shard{world}"},
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+        "parity": parity,
+        "derived": {"model_tflops": round(value * FLOP_PER_CU / 1e12, 1),
+                    "mfma_frac_whole_net": round(value / world * FLOP_PER_CU / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                    "hbm_layerwise_roofline_frac": round(value / world * LAYERWISE_BYTES_PER_CU / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernels": kernels},
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,8 +105,6 @@ def state_dict_spec(arch: int) -> "OrderedDict[str, tuple]":
     heads = HEAD_CLASSES[arch]
     cin = STEM_PLANES
     for li, c in enumerate(planes):
-        if li >= 1:
-            pass
         for bi in range(2):
             p = f"layer{li}.{bi}"
             spec[p + ".conv1.weight"] = (c, cin if bi == 0 else c, 3, 3)
@@ -121,11 +119,6 @@ def state_dict_spec(arch: int) -> "OrderedDict[str, tuple]":
             spec[f"branch{li}.weight"] = (heads[li - 1], c + 2)
             spec[f"branch{li}.bias"] = (heads[li - 1],)
     return spec
-
-
-def _module_order_spec(arch: int) -> "OrderedDict[str, tuple]":
-    """Same keys, in torch's registration order (branchN sits between layers in the ctor)."""
-    return state_dict_spec(arch)
 
 
 def make_state_dict(arch: int, weight_seed: int, head_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
@@ -211,3 +204,27 @@ def make_scalars(n: int, input_seed: int, first: int = 0):
     poc = randint(input_seed, "poc", n, 0, 600, offset=first).astype(np.int32)
     qp = randint(input_seed, "qp", n, 17, 47, offset=first).astype(np.int32)
     return poc, qp
+
+
+def make_patches_bulk(size: int, n: int, input_seed: int, first: int = 0):
+    """Vectorised KIND_TEXTURE-like generator for large batches (bench workload): same distribution as
+    make_patches(kind=KIND_TEXTURE) but drawn from bulk streams, so values differ from make_patches."""
+    px = size * size
+    nb = max(size // 16, 1)
+
+    def fast(stream, count, lo, hi, offset):  # multiply-shift range reduction on 32 random bits
+        r = (raw_u64(input_seed, stream, count, offset) >> np.uint64(32)) * np.uint64(hi - lo + 1)
+        return (r >> np.uint64(32)).astype(np.int16) + np.int16(lo)
+
+    org = np.empty((n, size, size), np.int16)
+    pred = np.empty((n, size, size), np.int16)
+    step = 256
+    for i0 in range(0, n, step):  # bounded temporaries
+        c = min(step, n - i0)
+        f = first + i0
+        base = fast("bulk/base", c * nb * nb, 64, 959, f * nb * nb).reshape(c, nb, 1, nb, 1)
+        base = np.broadcast_to(base, (c, nb, size // nb, nb, size // nb)).reshape(c, size, size)
+        o = np.clip(base + fast("bulk/tex", c * px, -48, 48, f * px).reshape(c, size, size), 0, 1023)
+        org[i0:i0 + c] = o
+        pred[i0:i0 + c] = np.clip(o + fast("bulk/noise", c * px, -40, 40, f * px).reshape(c, size, size), 0, 1023)
+    return org, pred
