@@ -47,7 +47,11 @@ def lib_path() -> str:
 
 
 def load_library():
-    """Loads the in-tree HIP library; raises if it has not been built (no silent fallback)."""
+    """Loads the in-tree HIP library; raises if it has not been built (no silent fallback).
+
+    torch is imported FIRST on purpose: in this image the working HIP runtime is the libamdhip64.so.7 bundled
+    with PyTorch-ROCm; loading ours first would bind the system copy of the same soname and HIP init fails."""
+    import torch  # noqa: F401
     global _LIB
     if _LIB is not None:
         return _LIB

@@ -80,6 +80,10 @@ int upload_model(mlt_ctx *ctx, mlt::Model &m) {
     HIP_TRY(ctx, hipMemcpy(pc.d_w, pc.w.data(), pc.w.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc((void **)&pc.d_bias, pc.bias.size() * 4));
     HIP_TRY(ctx, hipMemcpy(pc.d_bias, pc.bias.data(), pc.bias.size() * 4, hipMemcpyHostToDevice));
+    if (pc.has_sc) {
+      HIP_TRY(ctx, hipMalloc((void **)&pc.d_bias_sc, pc.bias_sc.size() * 4));
+      HIP_TRY(ctx, hipMemcpy(pc.d_bias_sc, pc.bias_sc.data(), pc.bias_sc.size() * 4, hipMemcpyHostToDevice));
+    }
     return MLT_OK;
   };
   int rc;
@@ -88,7 +92,6 @@ int upload_model(mlt_ctx *ctx, mlt::Model &m) {
     for (int b = 0; b < 2; ++b) {
       if ((rc = up(m.blocks[s][b].conv1))) return rc;
       if ((rc = up(m.blocks[s][b].conv2))) return rc;
-      if (m.blocks[s][b].has_sc && (rc = up(m.blocks[s][b].sc))) return rc;
     }
   for (int h = 0; h < m.n_heads; ++h) {
     mlt::Head &H = m.heads[h];
@@ -102,21 +105,32 @@ int upload_model(mlt_ctx *ctx, mlt::Model &m) {
 }
 
 void free_model(mlt::Model &m) {
-  auto fr = [](mlt::PackedConv &pc) { if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_bias) (void)hipFree(pc.d_bias); pc.d_w = nullptr; pc.d_bias = nullptr; };
+  auto fr = [](mlt::PackedConv &pc) {
+    if (pc.d_w) (void)hipFree(pc.d_w);
+    if (pc.d_bias) (void)hipFree(pc.d_bias);
+    if (pc.d_bias_sc) (void)hipFree(pc.d_bias_sc);
+    pc.d_w = nullptr; pc.d_bias = pc.d_bias_sc = nullptr;
+  };
   fr(m.stem);
   for (int s = 0; s < 5; ++s)
-    for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); fr(m.blocks[s][b].sc); }
+    for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); }
   for (int h = 0; h < 4; ++h) { if (m.heads[h].d_w) (void)hipFree(m.heads[h].d_w); if (m.heads[h].d_b) (void)hipFree(m.heads[h].d_b); m.heads[h].d_w = m.heads[h].d_b = nullptr; }
   m.on_device = false;
 }
 
-// activation workspace (bytes per CU) for size S: stem + 4 scratch maps of stage-0 size + one output per stage
+int gap_slots(int hw) { return hw >= 32 ? hw / 32 : 1; }
+
+// activation workspace (bytes per CU) for size S: 4 scratch maps of stage-0 size, one output per stage,
+// fp32 GAP partial sums per head.  The stem activation is never materialised (fused into layer0.0.conv1).
 size_t ws_per_cu(const mlt::Model &m, int S) {
-  size_t b = (size_t)S * S * 32 * 2;
   const int h0 = S / 2 > 0 ? S / 2 : 1;
-  b += 4 * (size_t)h0 * h0 * 32 * 2;
+  size_t b = 4 * ((size_t)h0 * h0 * 32 * 2 + 256);
   int h = S;
-  for (int s = 0; s < m.n_stages; ++s) { h = h / 2 > 0 ? h / 2 : 1; b += (size_t)h * h * m.planes[s] * 2; }
+  for (int s = 0; s < m.n_stages; ++s) {
+    h = h / 2 > 0 ? h / 2 : 1;
+    b += (size_t)h * h * m.planes[s] * 2 + 256;
+    if (s >= 1) b += (size_t)gap_slots(h * h) * m.planes[s] * 4 + 256;
+  }
   return b + 4096;
 }
 
@@ -163,11 +177,28 @@ struct Launch {
   }
 };
 
-int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const void *x, void *y, const void *res, bool relu, int *hout_out) {
+struct ConvIO {
+  const void *x = nullptr;    // input activation (ignored when raw planes are given)
+  void *y = nullptr;          // main output (may be NULL when only the GAP sums are needed)
+  void *y_sc = nullptr;       // shortcut output (conv carries a shortcut)
+  const void *res = nullptr;  // residual added before the ReLU
+  float *gap = nullptr;       // GAP partial sums
+  bool relu = false;
+  // stem-fused first conv: raw Pel planes
+  const int16_t *org = nullptr, *pred = nullptr;
+  long org_rs = 0, org_cs = 0, pred_rs = 0, pred_cs = 0;
+  const void *stem_w = nullptr;
+};
+
+int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const ConvIO &io, int *hout_out) {
   const int hout = hin / pc.stride > 0 ? hin / pc.stride : 1;
   *hout_out = hout;
+  const bool stem = io.org != nullptr;
   ConvArgs a{};
-  a.x = x; a.y = y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = res; a.n = n; a.relu = relu ? 1 : 0;
+  a.x = io.x; a.y = io.y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = io.res; a.n = n; a.relu = io.relu ? 1 : 0;
+  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc;
+  a.org = io.org; a.pred = io.pred; a.org_row_stride = io.org_rs; a.org_cu_stride = io.org_cs;
+  a.pred_row_stride = io.pred_rs; a.pred_cu_stride = io.pred_cs; a.stem_w = io.stem_w;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   const int MT = mlt_conv_tile_pixels(pc.cin, pc.cout, pc.stride, pc.taps);
   int tw = hout < 32 ? hout : 32;
@@ -183,20 +214,28 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const void
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
   a.pw_magic = (0x100000000ull + pw - 1) / pw;
   a.ph_magic = (0x100000000ull + ph - 1) / ph;
+  a.rw_magic = (0x100000000ull + pw + 1) / (pw + 2);
+  a.rh_magic = (0x100000000ull + ph + 1) / (ph + 2);
   a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
+  const int extra_lds = stem ? (spw * (ph + 2) * (pw + 2) * 4 + 15) / 16 * 16 : 0;
+  const int hw = hout * hout;
+  a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   const int grid_x = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
   char name[48];
-  std::snprintf(name, sizeof name, "conv%dx%d_s%d_%dto%d_h%d", pc.taps == 9 ? 3 : 1, pc.taps == 9 ? 3 : 1, pc.stride, pc.cin, pc.cout, hout);
-  const double px = (double)n * hout * hout;
-  const double flops = 2.0 * px * pc.cout * pc.cin * pc.taps;
-  const double bytes = (double)n * hin * hin * pc.cin * 2 + px * pc.cout * 2 * (res ? 2 : 1) + (double)pc.w.size() * 2;
+  std::snprintf(name, sizeof name, "%sconv3x3_s%d_%dto%d_h%d%s", stem ? "stem+" : "", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");
+  const double px = (double)n * hw;
+  const double flops = 2.0 * px * pc.cout * pc.cin * (pc.taps + (pc.has_sc ? 1 : 0)) + (stem ? 2.0 * n * hin * hin * 32 * 18 : 0.0);
+  const double in_bytes = stem ? (double)n * hin * hin * 4 : (double)n * hin * hin * pc.cin * 2;
+  const double bytes = in_bytes + px * pc.cout * 2 * ((io.y ? 1 : 0) + (io.y_sc ? 1 : 0) + (io.res ? 1 : 0)) + (double)pc.w.size() * 2;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.taps, a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.taps, pc.has_sc, stem, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
-  return debug_dump(ctx, name, y, (size_t)px * pc.cout * 2);
+  if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
+  if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
+  return MLT_OK;
 }
 
 // One chunk of n CUs through the whole network, everything on ctx->stream.
@@ -209,55 +248,59 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
   // carve the workspace
   char *p = ctx->ws;
   auto carve = [&](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return (void *)r; };
-  void *stem = carve((size_t)n * S * S * 32 * 2);
   const int h0 = S / 2 > 0 ? S / 2 : 1;
   void *pool[4];
   for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2);
   void *outs[5];
+  float *gaps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   {
     int h = S;
-    for (int s = 0; s < m.n_stages; ++s) { h = h / 2 > 0 ? h / 2 : 1; outs[s] = carve((size_t)n * h * h * m.planes[s] * 2); }
+    for (int s = 0; s < m.n_stages; ++s) {
+      h = h / 2 > 0 ? h / 2 : 1;
+      outs[s] = carve((size_t)n * h * h * m.planes[s] * 2);
+      if (s >= 1) gaps[s] = (float *)carve((size_t)n * gap_slots(h * h) * m.planes[s] * 4);
+    }
   }
   Launch L{ctx};
-  {  // stem (arch:277-278) fused with the preprocessing of EncCu.cpp:810-867
-    StemArgs a{};
-    a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
-    a.w = m.stem.d_w; a.y = stem; a.s_l = ilog2(S);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    char name[48];
-    std::snprintf(name, sizeof name, "stem_h%d", S);
-    if ((rc = L.prof_begin(name, 2.0 * n * S * S * 32 * 18, (double)n * S * S * (4 + 64), e0, e1))) return rc;
-    HIP_TRY(ctx, mlt_launch_stem(a, n, ctx->stream));
-    if ((rc = L.prof_end(e1))) return rc;
-    if ((rc = debug_dump(ctx, name, stem, (size_t)n * S * S * 32 * 2))) return rc;
-  }
-  const void *cur = stem;
+  const void *cur = nullptr;
   int h = S;
   HeadArgs ha{};
   for (int s = 0; s < m.n_stages; ++s) {
-    int hout = h;
-    // block 0 (stride 2, projection shortcut): t = relu(bn1(conv1 x)); sc = bn(conv1x1 x); b0 = relu(bn2(conv2 t) + sc)
+    int hout = h, h2;
+    const bool last = s == m.n_stages - 1;
+    // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
+    // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
     mlt::Block &B0 = m.blocks[s][0];
-    if ((rc = run_conv(ctx, B0.conv1, n, h, cur, pool[0], nullptr, true, &hout))) return rc;
-    if ((rc = run_conv(ctx, B0.sc, n, h, cur, pool[1], nullptr, false, &hout))) return rc;
-    int h2;
-    if ((rc = run_conv(ctx, B0.conv2, n, hout, pool[0], pool[2], pool[1], true, &h2))) return rc;
+    ConvIO io;
+    io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
+    if (s == 0) {
+      io.org = d_org; io.pred = d_pred; io.org_rs = org_rs; io.org_cs = org_cs; io.pred_rs = pred_rs; io.pred_cs = pred_cs;
+      io.stem_w = m.stem.d_w;
+    }
+    if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+    io = ConvIO();
+    io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
+    if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
     // block 1 (identity shortcut)
     mlt::Block &B1 = m.blocks[s][1];
-    if ((rc = run_conv(ctx, B1.conv1, n, hout, pool[2], pool[3], nullptr, true, &h2))) return rc;
-    if ((rc = run_conv(ctx, B1.conv2, n, hout, pool[3], outs[s], pool[2], true, &h2))) return rc;
+    io = ConvIO();
+    io.x = pool[2]; io.y = pool[3]; io.relu = true;
+    if ((rc = run_conv(ctx, B1.conv1, n, hout, io, &h2))) return rc;
+    io = ConvIO();
+    io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
+    if ((rc = run_conv(ctx, B1.conv2, n, hout, io, &h2))) return rc;
     cur = outs[s];
     h = hout;
     if (s >= 1) {
       const int hd = s - 1;
-      ha.feat[hd] = outs[s]; ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
+      ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
       ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
     }
   }
   ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if ((rc = L.prof_begin("gap_heads", 0.0, 0.0, e0, e1))) return rc;
+    if ((rc = L.prof_begin("heads", 0.0, 0.0, e0, e1))) return rc;
     HIP_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
     if ((rc = L.prof_end(e1))) return rc;
   }

@@ -19,18 +19,22 @@ struct ConvArgs {
   uint64_t pw_magic, ph_magic; // ceil(2^32 / d)
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
-};
-
-struct StemArgs {
-  const int16_t *org, *pred;       // Pel planes
+  // SC variant: second output = bn(conv1x1_stride2(x)) (projection shortcut, arch:44-50)
+  void *y_sc;
+  const float *bias_sc;
+  // fp32 global-average-pool partial sums [n][gap_slots][COUT] (NULL: none); gap_l = log2(lanes per sample)
+  float *gap;
+  int gap_slots, gap_l;
+  // STEM variant: raw Pel planes instead of x
+  const int16_t *org, *pred;
   long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
-  const void *w;                   // packed stem weights (2 KiB)
-  void *y;                         // [n][S][S][32] fp16
-  int s_l;                         // log2(S)
+  const void *stem_w;          // packed stem weights (2 KiB)
+  uint64_t rw_magic, rh_magic; // raw patch dims are (ph + 2) x (pw + 2)
 };
 
 struct HeadArgs {
-  const void *feat[MLT_MAX_HEADS_K];  // stage outputs [n][hw][C] fp16
+  const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
+  int slots[MLT_MAX_HEADS_K];
   const float *w[MLT_MAX_HEADS_K];    // [classes][C+2] fp32
   const float *b[MLT_MAX_HEADS_K];
   int c[MLT_MAX_HEADS_K], hw[MLT_MAX_HEADS_K], classes[MLT_MAX_HEADS_K];
@@ -40,8 +44,8 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, const ConvArgs &a, int grid_x, hipStream_t st);
-hipError_t mlt_launch_stem(const StemArgs &a, int n, hipStream_t st);
+hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, bool sc, bool stem, const ConvArgs &a, int grid_x,
+                           int extra_lds, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);
 int mlt_conv_tile_pixels(int cin, int cout, int stride, int taps);  // output pixels per workgroup
 int mlt_conv_cout_tile(int cout);                                   // output channels per workgroup

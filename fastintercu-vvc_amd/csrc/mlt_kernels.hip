@@ -4,9 +4,9 @@
 // and mlt_cu_or_pq_arch.py:96-128; preprocessing: vtm-mlt-cpp/source/Lib/EncoderLib/EncCu.cpp:810-877.
 //
 // Data layout: activations NHWC fp16 in HBM; weights BN-folded, fp16, pre-packed on the host in
-// MFMA A-fragment order (see mlt_model.cpp) so a wave fetches one fragment as 64 x 16 contiguous
-// bytes (LDS-DMA friendly, conflict-free ds_read_b128).  Accumulation, bias, residual add, GAP and
-// the heads are fp32.
+// MFMA A-fragment order (mlt_model.cpp) so a wave fetches one fragment as 64 x 16 contiguous bytes
+// (LDS-DMA friendly, conflict-free ds_read_b128).  Accumulation, bias, residual add, global average
+// pooling and the heads are fp32.
 //
 // MFMA orientation: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]  (weights = A, activations = B).
 // With v_mfma_f32_32x32x16_f16 lane l (p = l&31, h = l>>5) supplies B[k = 8h+j][col p] = 8 consecutive
@@ -35,14 +35,55 @@ __device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_bas
 
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint64_t magic) { return (uint32_t)(((uint64_t)n * magic) >> 32); }
 
+// (org, |org - pred|) as an exact-integer fp16 pair: EncCu.cpp:816,827 (u16 cast), :833 (absdiff),
+// :848-867 (clip to [0,1] after the 1/1023 scale == clip the integer to [0,1023]; the scale itself
+// lives in the stem weights).
+__device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
+  uint16_t o = (uint16_t)so, q = (uint16_t)sp;
+  uint16_t r = o > q ? o - q : q - o;
+  o = o > 1023 ? 1023 : o;
+  r = r > 1023 ? 1023 : r;
+  half2v hv;
+  hv[0] = (_Float16)(float)o;
+  hv[1] = (_Float16)(float)r;
+  return *(uint32_t *)&hv;
+}
+
+// Stem MFMA for one 32-pixel block: B fragments gathered from the raw (org,resi) LDS patch.
+// k = 2*tap + channel; k-step 0: lane half h supplies taps 4h..4h+3; k-step 1: tap 8 (h = 0), rest zero.
+__device__ __forceinline__ float16v stem_mma(const uint32_t *raw, int ridx, int rw, int h, half8 a0, half8 a1) {
+  uint32_t d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = 4 * h + e;
+    const int dy = t / 3, dx = t - dy * 3;
+    d[e] = raw[ridx + dy * rw + dx];
+  }
+  const uint32_t d8 = h == 0 ? raw[ridx + 2 * rw + 2] : 0u;
+  half8 b0, b1;
+  uint32_t *b0w = (uint32_t *)&b0, *b1w = (uint32_t *)&b1;
+  b0w[0] = d[0]; b0w[1] = d[1]; b0w[2] = d[2]; b0w[3] = d[3];
+  b1w[0] = d8; b1w[1] = 0; b1w[2] = 0; b1w[3] = 0;
+  float16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic conv (3x3 pad 1 or 1x1 pad 0, stride 1 or 2), NHWC fp16 -> NHWC fp16, fp32 accumulate.
 // One workgroup: MT = 32*WPB*WAVES_P output pixels (SPW samples x TH x TW) x CT = 32*WCB*WAVES_C
 // output channels.  Per 64-or-32-channel input chunk the (haloed) input patch is staged ONCE in LDS
-// and reused by all taps; weights stream through a double-buffered LDS ring by LDS-DMA, one group
-// of GT taps per step.
+// and reused by all taps; weights stream through a double-buffered LDS ring by LDS-DMA, GT taps per step.
+//   SC   : the block's 1x1 stride-2 projection shortcut (arch:44-50) rides along as weight "tap 9" on the
+//          same patch and leaves through a second accumulator / output (y_sc).
+//   STEM : the patch is not loaded but COMPUTED: raw Pel planes -> stem conv (arch:277-278) -> LDS, so the
+//          stem activation (1 MiB per 128x128 CU) never touches HBM.
+//   gap  : fp32 per-channel partial sums of the activated output (global average pooling, arch:282).
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int KC = (CIN % 64 == 0) ? 64 : 32;
   constexpr int NCHUNK = CIN / KC;
@@ -53,11 +94,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   constexpr int CT = 32 * CBT;
   constexpr int NW = WAVES_C * WAVES_P;
   constexpr int NT = 64 * NW;
-  constexpr int NG = TAPS / GT;
+  constexpr int TT = TAPS + (SC ? 1 : 0);  // weight steps per chunk (taps + shortcut)
+  constexpr int NG = TT / GT;
   constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step
   constexpr int PAD = TAPS == 9 ? 1 : 0;
-  static_assert(TAPS % GT == 0, "tap grouping");
+  constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
+  static_assert(TT % GT == 0, "tap grouping");
   static_assert(COUT % CT == 0, "cout tiling");
+  static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
+  static_assert(!STEM || (CIN == 32 && NCHUNK == 1), "stem feeds the first 32-channel conv");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *patch = smem;
@@ -86,54 +131,113 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   // ---- per-lane pixel mapping for this wave's pixel blocks ----
   int base[WPB];      // LDS byte offset of (pixel, tap (0,0), slot h)
   int opix[WPB];      // output pixel index (flattened n,y,x) or -1
+  int gidx[WPB];      // gap partial-sum row (sample * nslots + slot) or -1
 #pragma unroll
   for (int j = 0; j < WPB; ++j) {
     int m = (wp * WPB + j) * 32 + p;
     bool ok = m < m_valid;
     int mm = ok ? m : 0;
     int x = mm & (TW - 1), y = (mm >> tw_l) & (TH - 1), s = mm >> (tw_l + th_l);
-    base[j] = ((s * PH + y * STRIDE) * RP + (STRIDE == 2 ? x : x)) * PS + h * 16;
+    base[j] = ((s * PH + y * STRIDE) * RP + x) * PS + h * 16;
     int oy = (ty << th_l) + y, ox = (tx << tw_l) + x;
-    opix[j] = (ok && (n0 + s) < a.n) ? ((((n0 + s) << hout_l) + oy) << hout_l) + ox : -1;
+    ok = ok && (n0 + s) < a.n;
+    opix[j] = ok ? ((((n0 + s) << hout_l) + oy) << hout_l) + ox : -1;
+    const int tile_in_sample = (ty << txs_l) + tx;
+    const int slot = ((tile_in_sample << (tw_l + th_l)) + (mm & ((1 << (tw_l + th_l)) - 1))) >> 5;
+    gidx[j] = ok ? (n0 + s) * a.gap_slots + slot : -1;
   }
 
   float16v acc[WCB][WPB];
+  float16v acc_sc[SCW][SPB];
 #pragma unroll
   for (int i = 0; i < WCB; ++i)
 #pragma unroll
     for (int j = 0; j < WPB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < SCW; ++i)
+#pragma unroll
+    for (int j = 0; j < SPB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
 
-  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TAPS * (KS * CBT * 1024);
-  const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
+  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
   const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
 
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
     if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk's patch / weights
-    // ---- stage the input patch chunk: global (16 B / lane) -> LDS ----
-    for (int it = tid; it < patch_items; it += NT) {
-      int slot = it & (SLOTS - 1);
-      uint32_t pix = (uint32_t)it / SLOTS;
-      uint32_t r = udiv_magic(pix, a.pw_magic);
-      int px = pix - r * PW;
-      uint32_t s = udiv_magic(r, a.ph_magic);
-      int py = r - s * PH;
-      int iy = iy0 + py, ix = ix0 + px;
-      half8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
-      if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
-        const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
-                              chunk * KC + slot * 8;
-        v = *(const half8 *)src;
+    if constexpr (STEM) {
+      // ---- raw (org,resi) patch -> LDS, then the stem conv writes the 32-channel patch ----
+      uint32_t *raw = (uint32_t *)(wring + 2 * WCHUNK);
+      const int RH = PH + 2, RW = PW + 2;
+      const int raw_items = (1 << spw_l) * RH * RW;
+      for (int it = tid; it < raw_items; it += NT) {
+        uint32_t r = udiv_magic(it, a.rw_magic);
+        int rx = it - r * RW;
+        uint32_t s = udiv_magic(r, a.rh_magic);
+        int ry = r - s * RH;
+        int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+        uint32_t v = 0;
+        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n)
+          v = prep_pair(a.org[(size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix],
+                        a.pred[(size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix]);
+        raw[it] = v;
       }
-      int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-      *(half8 *)(patch + ((s * PH + py) * RP + col) * PS + slot * 16) = v;
+      const half8 a0 = *(const half8 *)((const char *)a.stem_w + lane * 16);
+      const half8 a1 = *(const half8 *)((const char *)a.stem_w + 1024 + lane * 16);
+      __syncthreads();
+      const int stem_px = (1 << spw_l) * PH * PW;
+      for (int pb = wave; pb * 32 < stem_px; pb += NW) {
+        int m = pb * 32 + p;
+        bool ok = m < stem_px;
+        int mm = ok ? m : 0;
+        uint32_t r = udiv_magic(mm, a.pw_magic);
+        int px = mm - r * PW;
+        uint32_t s = udiv_magic(r, a.ph_magic);
+        int py = r - s * PH;
+        float16v v = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0, a1);
+        int iy = iy0 + py, ix = ix0 + px;
+        // outside the picture the conv sees ZERO padding of the stem activation, not stem(padded input)
+        const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n;
+        if (ok) {
+          int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+          char *dst = patch + ((s * PH + py) * RP + col) * PS + 8 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)v[4 * q + e] : (_Float16)0.f;
+            *(half4 *)(dst + 16 * q) = o;
+          }
+        }
+      }
+    } else {
+      // ---- stage the input patch chunk: global (16 B / lane) -> LDS ----
+      const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
+      for (int it = tid; it < patch_items; it += NT) {
+        int slot = it & (SLOTS - 1);
+        uint32_t pix = (uint32_t)it / SLOTS;
+        uint32_t r = udiv_magic(pix, a.pw_magic);
+        int px = pix - r * PW;
+        uint32_t s = udiv_magic(r, a.ph_magic);
+        int py = r - s * PH;
+        int iy = iy0 + py, ix = ix0 + px;
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
+          const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
+                                chunk * KC + slot * 8;
+          v = *(const half8 *)src;
+        }
+        int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+        *(half8 *)(patch + ((s * PH + py) * RP + col) * PS + slot * 16) = v;
+      }
     }
     // ---- first weight step of this chunk ----
     {
-      const char *src = wsrc + (size_t)(chunk * TAPS) * (KS * CBT * 1024);
+      const char *src = wsrc + (size_t)(chunk * TT) * (KS * CBT * 1024);
       for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + pi * 1024 + lane * 16, wring + pi * 1024);
     }
     __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
@@ -142,16 +246,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
     for (int g = 0; g < NG; ++g) {
       char *wcur = wring + (g & 1) * WCHUNK;
       if (g + 1 < NG) {
-        const char *src = wsrc + (size_t)(chunk * TAPS + (g + 1) * GT) * (KS * CBT * 1024);
+        const char *src = wsrc + (size_t)(chunk * TT + (g + 1) * GT) * (KS * CBT * 1024);
         char *dst = wring + ((g + 1) & 1) * WCHUNK;
         for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + pi * 1024 + lane * 16, dst + pi * 1024);
       }
 #pragma unroll
       for (int tt = 0; tt < GT; ++tt) {
         const int t = g * GT + tt;
+        const bool is_sc = SC && t == TAPS;
         int toff;
         if (TAPS == 9) {
-          int dy = t / 3, dx = t - dy * 3;
+          const int te = is_sc ? 4 : t;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+          int dy = te / 3, dx = te - dy * 3;
           toff = STRIDE == 2 ? (dy * RP + (dx & 1) * HALF + (dx >> 1)) * PS : (dy * RP + dx) * PS;
         } else {
           toff = 0;
@@ -167,152 +273,155 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
             af[i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
 #pragma unroll
           for (int j = 0; j < WPB; ++j) bf[j] = *(const half8 *)(bp[j] + ks * 32);
+          if (is_sc) {
+            if constexpr (SC) {
 #pragma unroll
-          for (int i = 0; i < WCB; ++i)
+              for (int i = 0; i < WCB; ++i)
 #pragma unroll
-            for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WPB; ++j) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc_sc[i][j], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < WCB; ++i)
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          }
         }
       }
       if (g + 1 < NG) __syncthreads();  // next weights landed (vmcnt(0)) + everyone finished this buffer
     }
   }
 
-  // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC, 8 B per register quad ----
+  // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
+  const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
     const int cbase = ctile * CT + (wc * WCB + i) * 32 + 4 * h;
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
-      if (opix[j] < 0) continue;
-      const size_t o = (size_t)opix[j] * COUT + cbase;
+      const bool ok = opix[j] >= 0;
+      const size_t o = (size_t)(ok ? opix[j] : 0) * COUT + cbase;
+      float v[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4v b = *(const float4v *)(a.bias + cbase + 8 * q);
-        float v0 = acc[i][j][4 * q + 0] + b[0], v1 = acc[i][j][4 * q + 1] + b[1];
-        float v2 = acc[i][j][4 * q + 2] + b[2], v3 = acc[i][j][4 * q + 3] + b[3];
-        if (a.res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + b[e];
+        if (a.res && ok) {
           const half4 r = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
-          v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)r[e];
         }
         if (a.relu) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(v[4 * q + e], 0.f);
         }
-        half4 out;
-        out[0] = (_Float16)v0; out[1] = (_Float16)v1; out[2] = (_Float16)v2; out[3] = (_Float16)v3;
-        *(half4 *)((_Float16 *)a.y + o + 8 * q) = out;
+        if (a.y && ok) {
+          half4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (_Float16)v[4 * q + e];
+          *(half4 *)((_Float16 *)a.y + o + 8 * q) = out;
+        }
+        if constexpr (SC) {
+          if (ok) {
+            const float4v bs = *(const float4v *)(a.bias_sc + cbase + 8 * q);
+            half4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = (_Float16)(acc_sc[i][j][4 * q + e] + bs[e]);
+            *(half4 *)((_Float16 *)a.y_sc + o + 8 * q) = out;
+          }
+        }
+      }
+      if (a.gap) {
+        // Sum over the pixels of one sample inside this 32-pixel block, in fp32, BEFORE any fp16 rounding.
+        // Halving butterfly: after the steps for lane bits 0..3 each lane holds ONE channel's sum, channel
+        // register index = b0*8 + b1*4 + b2*2 + b3 (b_k = bit k of p).  Fixed order => deterministic.
+        if (!ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
+        if (gl == 0) {
+          if (ok) {
+            float *grow = a.gap + (size_t)gidx[j] * COUT + cbase;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) grow[8 * q + e] = v[4 * q + e];
+          }
+        } else {
+          float r8[8], r4[4];
+          {
+            const bool up = p & 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float send = up ? v[k] : v[8 + k], keep = up ? v[8 + k] : v[k];
+              r8[k] = keep + __shfl_xor(send, 1, 64);
+            }
+          }
+          {
+            const bool up = p & 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float send = up ? r8[k] : r8[4 + k], keep = up ? r8[4 + k] : r8[k];
+              r4[k] = keep + __shfl_xor(send, 2, 64);
+            }
+          }
+          if (gl == 2) {  // 4 pixels per sample: lane holds 4 channel sums, register index (p&1)*8 + ((p>>1)&1)*4 + k
+            if (ok) {
+              float *grow = a.gap + (size_t)gidx[j] * COUT + cbase;
+              const int ri = (p & 1) * 8 + ((p >> 1) & 1) * 4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) grow[8 * ((ri + k) >> 2) + ((ri + k) & 3)] = r4[k];
+            }
+          } else {
+            float r2[2], r1;
+            {
+              const bool up = p & 4;
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                float send = up ? r4[k] : r4[2 + k], keep = up ? r4[2 + k] : r4[k];
+                r2[k] = keep + __shfl_xor(send, 4, 64);
+              }
+            }
+            {
+              const bool up = p & 8;
+              float send = up ? r2[0] : r2[1], keep = up ? r2[1] : r2[0];
+              r1 = keep + __shfl_xor(send, 8, 64);
+            }
+            if (gl == 5) r1 += __shfl_xor(r1, 16, 64);
+            // all pixels of the group belong to one sample: take the row from the group's first lane
+            const int grp_lane0 = gl == 5 ? 0 : (p & 16);
+            const int g0 = __shfl(gidx[j], (h << 5) + grp_lane0, 64);
+            if (g0 >= 0 && (gl == 4 || p < 16)) {
+              const int ri = (p & 1) * 8 + ((p >> 1) & 1) * 4 + ((p >> 2) & 1) * 2 + ((p >> 3) & 1);
+              a.gap[(size_t)g0 * COUT + cbase + 8 * (ri >> 2) + (ri & 3)] = r1;
+            }
+          }
+        }
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stem: raw Pel (int16) org/pred -> [org, |org-pred|] (exact integers in fp16; the 1/1023 scale of
-// EncCu.cpp:836,838 is folded into the weights) -> conv3x3 2->32 (no BN, no ReLU: arch:277-278).
-// K = 9 taps x 2 channels = 18, zero-padded to 32 (two MFMA k-steps).
-// Tile: 8 x 32 output pixels of one CU per workgroup (4 waves x 2 pixel blocks).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
-  __shared__ uint32_t patch[340];  // (org, resi) fp16 pair per pixel; max (8+2)*(32+2)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = lane & 31, h = lane >> 5;
-  const int S = 1 << a.s_l;
-  const int tw_eff = S < 32 ? S : 32;                       // S = 16: 16 x 16 tile, else 8 x 32
-  const int th_eff = (256 / tw_eff) > S ? S : (256 / tw_eff);
-  const int txs = S / tw_eff, tys = S / th_eff;
-  const int mt = blockIdx.x;
-  const int tx = mt % txs, ty = (mt / txs) % tys, n = mt / (txs * tys);
-  const int pw = tw_eff + 2, ph = th_eff + 2;
-  const int16_t *org = a.org + (size_t)n * a.org_cu_stride;
-  const int16_t *prd = a.pred + (size_t)n * a.pred_cu_stride;
-  for (int it = tid; it < ph * pw; it += 256) {
-    int py = it / pw, px = it - py * pw;
-    int iy = ty * th_eff + py - 1, ix = tx * tw_eff + px - 1;
-    uint32_t v = 0;
-    if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
-      uint16_t o = (uint16_t)org[(size_t)iy * a.org_row_stride + ix];   // EncCu.cpp:816
-      uint16_t q = (uint16_t)prd[(size_t)iy * a.pred_row_stride + ix];  // EncCu.cpp:827
-      uint16_t r = o > q ? o - q : q - o;                               // cv::absdiff, EncCu.cpp:833
-      // clip to [0,1] after *1/1023 (EncCu.cpp:848-867) == clip the integer to [0,1023]
-      o = o > 1023 ? 1023 : o;
-      r = r > 1023 ? 1023 : r;
-      half2v hv;
-      hv[0] = (_Float16)(float)o;
-      hv[1] = (_Float16)(float)r;
-      v = *(uint32_t *)&hv;
-    }
-    patch[py * pw + px] = v;
-  }
-  // A fragments: 2 k-steps x 1 channel block, straight from global (2 KiB, L2-resident)
-  const half8 a0 = *(const half8 *)((const char *)a.w + lane * 16);
-  const half8 a1 = *(const half8 *)((const char *)a.w + 1024 + lane * 16);
-  __syncthreads();
-  const int npix = th_eff * tw_eff;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int m = (wave * 2 + j) * 32 + p;
-    bool ok = m < npix;
-    int mm = ok ? m : 0;
-    int x = mm % tw_eff, y = mm / tw_eff;
-    // k-step 0: lane half h supplies taps 4h..4h+3 (k = 2*tap + channel); k-step 1: tap 8 (h = 0 only)
-    uint32_t d[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int t = 4 * h + e;
-      int dy = t / 3, dx = t - dy * 3;
-      d[e] = patch[(y + dy) * pw + x + dx];
-    }
-    uint32_t d8 = h == 0 ? patch[(y + 2) * pw + x + 2] : 0u;
-    half8 b0, b1;
-    uint32_t *b0w = (uint32_t *)&b0, *b1w = (uint32_t *)&b1;
-    b0w[0] = d[0]; b0w[1] = d[1]; b0w[2] = d[2]; b0w[3] = d[3];
-    b1w[0] = d8; b1w[1] = 0; b1w[2] = 0; b1w[3] = 0;
-    float16v acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-    if (ok) {
-      int oy = ty * th_eff + y, ox = tx * tw_eff + x;
-      _Float16 *dst = (_Float16 *)a.y + ((((size_t)n << a.s_l) + oy) << a.s_l) * 32 + (size_t)ox * 32 + 4 * h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        half4 out;
-        out[0] = (_Float16)acc[4 * q + 0]; out[1] = (_Float16)acc[4 * q + 1];
-        out[2] = (_Float16)acc[4 * q + 2]; out[3] = (_Float16)acc[4 * q + 3];
-        *(half4 *)(dst + 8 * q) = out;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// GAP + heads + argmax (arch:282-297, EncCu.cpp:913-921).  One workgroup per CU; fp32 throughout.
-// logits_k = W_k . [mean_hw(feat) (C floats), poc, qp] + b_k ; split = first maximal index.
+// Heads + argmax (arch:282-297, EncCu.cpp:913-921).  One workgroup per CU; fp32 throughout.
+// feat = (sum of the GAP partial sums written by the stage's last conv) / HW
+// logits_k = W_k . [feat (C floats), poc, qp] + b_k ; split = first maximal index (torch.argmax).
 // Every class of a head runs the identical operation sequence, so identical rows tie exactly.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gap_heads_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
   __shared__ float feat[256 + 2];
   __shared__ float lg[MLT_MAX_LOGITS_K];
-  __shared__ float part[256];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float fpoc = (float)a.poc[n], fqp = (float)a.qp[n];  // EncCu.cpp:881-882 (int -> float, exact)
   int lo = 0;
   for (int hd = 0; hd < a.n_heads; ++hd) {
-    const int C = a.c[hd], hw = a.hw[hd], K = a.classes[hd];
-    const _Float16 *f = (const _Float16 *)a.feat[hd] + (size_t)n * hw * C;
-    {
-      const int ng = 256 / C, g = tid / C, c = tid - g * C;  // pixel groups x channels
-      if (g < ng) {
-        float s = 0.f;
-        for (int i = g; i < hw; i += ng) s += (float)f[(size_t)i * C + c];
-        part[g * C + c] = s;
-      }
-      __syncthreads();
-      if (tid < C) {
-        float s = 0.f;
-        for (int gg = 0; gg < ng; ++gg) s += part[gg * C + tid];
-        feat[tid] = s / (float)hw;
-      }
+    const int C = a.c[hd], K = a.classes[hd], slots = a.slots[hd];
+    if (tid < C) {
+      const float *g = a.gap[hd] + (size_t)n * slots * C + tid;
+      float s = 0.f;
+      for (int i = 0; i < slots; ++i) s += g[(size_t)i * C];
+      feat[tid] = s / (float)a.hw[hd];
     }
     if (tid == 0) { feat[C] = fpoc; feat[C + 1] = fqp; }
     __syncthreads();
@@ -341,48 +450,44 @@ __global__ __launch_bounds__(256) void gap_heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
-static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, WCB, WPB, WAVES_C, WAVES_P, GT>;
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, WCB, WPB, WAVES_C, WAVES_P, GT>;
   constexpr int KC = (CIN % 64 == 0) ? 64 : 32;
   constexpr int CBT = WCB * WAVES_C;
-  const int lds = a.patch_bytes + 2 * GT * (KC / 16) * CBT * 1024;
-  static int configured = 0;
-  if (configured < lds) {
+  const int lds = a.patch_bytes + 2 * GT * (KC / 16) * CBT * 1024 + extra_lds;
+  static bool configured = false;
+  if (!configured) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    configured = 160 * 1024;
+    configured = true;
   }
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   dim3 grid(grid_x, COUT / (32 * CBT));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_C * WAVES_P), lds, st, a);
   return hipGetLastError();
 }
 
-// wave tiling per output width (must match conv_plan() in mlt_model.cpp)
-#define CONV_CASE(CIN, COUT, STRIDE, TAPS, WCB, WPB, WC, WP, GT)                                  \
-  if (cin == CIN && cout == COUT && stride == STRIDE && taps == TAPS)                             \
-    return launch_conv_t<CIN, COUT, STRIDE, TAPS, WCB, WPB, WC, WP, GT>(a, grid_x, st);
+// wave tiling per layer shape (mlt_conv_tile_pixels / mlt_conv_cout_tile must agree)
+#define CONV_CASE(CIN, COUT, STRIDE, TAPS, SCF, STEMF, WCB, WPB, WC, WP, GT)                                  \
+  if (cin == CIN && cout == COUT && stride == STRIDE && taps == TAPS && sc == SCF && stem == STEMF)           \
+    return launch_conv_t<CIN, COUT, STRIDE, TAPS, SCF, STEMF, WCB, WPB, WC, WP, GT>(a, grid_x, extra_lds, st);
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, const ConvArgs &a, int grid_x, hipStream_t st) {
-  //        CIN  COUT S  T  WCB WPB WC WP GT
-  CONV_CASE(32, 32, 1, 9, 1, 2, 1, 4, 9)
-  CONV_CASE(32, 32, 2, 9, 1, 1, 1, 4, 9)
-  CONV_CASE(32, 32, 2, 1, 1, 1, 1, 4, 1)
-  CONV_CASE(32, 64, 2, 9, 2, 1, 1, 4, 3)
-  CONV_CASE(32, 64, 2, 1, 2, 1, 1, 4, 1)
-  CONV_CASE(64, 64, 1, 9, 2, 2, 1, 4, 1)
-  CONV_CASE(64, 128, 2, 9, 2, 2, 2, 2, 1)
-  CONV_CASE(64, 128, 2, 1, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 128, 1, 9, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 256, 2, 9, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 256, 2, 1, 2, 2, 2, 2, 1)
-  CONV_CASE(256, 256, 1, 9, 2, 2, 2, 2, 1)
+hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, bool sc, bool stem, const ConvArgs &a, int grid_x,
+                           int extra_lds, hipStream_t st) {
+  //        CIN  COUT S  T  SC     STEM   WCB WPB WC WP GT
+  CONV_CASE(32, 32, 2, 9, true, true, 1, 1, 1, 4, 10)
+  CONV_CASE(32, 32, 1, 9, false, false, 1, 2, 1, 4, 9)
+  CONV_CASE(32, 64, 2, 9, true, false, 2, 1, 1, 4, 5)
+  CONV_CASE(64, 64, 1, 9, false, false, 2, 2, 1, 4, 1)
+  CONV_CASE(64, 128, 2, 9, true, false, 2, 2, 2, 2, 1)
+  CONV_CASE(128, 128, 1, 9, false, false, 2, 2, 2, 2, 1)
+  CONV_CASE(128, 256, 2, 9, true, false, 2, 2, 2, 2, 1)
+  CONV_CASE(256, 256, 1, 9, false, false, 2, 2, 2, 2, 1)
   // CU model (planes 32/64/96/128/256)
-  CONV_CASE(64, 96, 2, 9, 3, 1, 1, 4, 1)
-  CONV_CASE(64, 96, 2, 1, 3, 1, 1, 4, 1)
-  CONV_CASE(96, 96, 1, 9, 3, 1, 1, 4, 3)
-  CONV_CASE(96, 128, 2, 9, 2, 2, 2, 2, 3)
-  CONV_CASE(96, 128, 2, 1, 2, 2, 2, 2, 1)
+  CONV_CASE(64, 96, 2, 9, true, false, 3, 1, 1, 4, 1)
+  CONV_CASE(96, 96, 1, 9, false, false, 3, 1, 1, 4, 3)
+  CONV_CASE(96, 128, 2, 9, true, false, 2, 2, 2, 2, 2)
   return hipErrorInvalidValue;
 }
 
@@ -394,16 +499,7 @@ int mlt_conv_tile_pixels(int cin, int cout, int stride, int taps) {
 
 int mlt_conv_cout_tile(int cout) { return cout >= 128 ? 128 : cout; }
 
-hipError_t mlt_launch_stem(const StemArgs &a, int n, hipStream_t st) {
-  const int S = 1 << a.s_l;
-  const int tw = S < 32 ? S : 32;
-  int th = 256 / tw; if (th > S) th = S;
-  const int tiles = (S / tw) * (S / th);
-  hipLaunchKernelGGL(stem_kernel, dim3(n * tiles), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st) {
-  hipLaunchKernelGGL(gap_heads_kernel, dim3(n), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(heads_kernel, dim3(n), dim3(256), 0, st, a);
   return hipGetLastError();
 }

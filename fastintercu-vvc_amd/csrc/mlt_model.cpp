@@ -93,23 +93,28 @@ static void fold_scale(const BlobView &b, const std::string &prefix, int c, std:
   }
 }
 
-// w: torch layout [cout][cin][taps]; scale: per-cout multiplier.  Output: fragment-packed fp16 (see header).
-static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> &scale) {
-  const int cin = pc.cin, cout = pc.cout, taps = pc.taps;
+// w: torch layout [cout][cin][taps]; scale: per-cout multiplier; w_sc (optional): [cout][cin] 1x1 shortcut.
+// Output: fragment-packed fp16 (see header).
+static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> &scale, const float *w_sc,
+                      const std::vector<double> &scale_sc) {
+  const int cin = pc.cin, cout = pc.cout, taps = pc.taps, tt = taps + (w_sc ? 1 : 0);
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
-  pc.w.assign((size_t)cout * cin * taps, 0);
+  pc.w.assign((size_t)cout * cin * tt, 0);
   for (int co = 0; co < cout; ++co) {
     const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
     for (int ci = 0; ci < cin; ++ci) {
       const int chunk = ci / KC, kk = ci % KC, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
+      auto at = [&](int t) -> uint16_t & {
+        return pc.w[((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j];
+      };
       double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of this (co, ci)
       for (int t = 0; t < taps; ++t) {
         const double exact = (double)w[((size_t)co * cin + ci) * taps + t] * scale[co];
         const uint16_t q = f32_to_f16((float)(exact - err));
         err += (double)f16_to_f32(q) - exact;
-        const size_t idx = ((((size_t)(ctile * NCHUNK + chunk) * taps + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j;
-        pc.w[idx] = q;
+        at(t) = q;
       }
+      if (w_sc) at(taps) = f32_to_f16((float)((double)w_sc[(size_t)co * cin + ci] * scale_sc[co]));
     }
   }
 }
@@ -168,24 +173,32 @@ bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
     for (int bi = 0; bi < 2; ++bi) {
       Block &B = m.blocks[s][bi];
       const int bin = bi == 0 ? cin : c, st = bi == 0 ? 2 : 1;  // _make_layer strides [2,1] (arch:265-271)
-      auto make = [&](PackedConv &pc, const char *wname, const char *bnname, int ci, int taps, int stride) -> bool {
-        pc.cin = ci; pc.cout = c; pc.taps = taps; pc.stride = stride;
+      auto make = [&](PackedConv &pc, const char *wname, const char *bnname, int ci, int stride, bool with_sc) -> bool {
+        pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc;
         pc.kc = (ci % 64 == 0) ? 64 : 32;
         pc.ct = c >= 128 ? 128 : c;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, wname);
-        const float *w = b.find(nm, (uint64_t)c * ci * taps, err);
+        const float *w = b.find(nm, (uint64_t)c * ci * 9, err);
         if (!w) return false;
-        std::vector<double> scale;
+        std::vector<double> scale, scale_sc;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, bnname);
         fold_scale(b, nm, c, scale, pc.bias, err);
         if (!err.empty()) return false;
-        pack_conv(pc, w, scale);
+        const float *wsc = nullptr;
+        if (with_sc) {  // shortcut = Sequential(conv1x1(stride), BN) (arch:46-50)
+          std::snprintf(nm, sizeof nm, "layer%d.%d.shortcut.0.weight", s, bi);
+          wsc = b.find(nm, (uint64_t)c * ci, err);
+          if (!wsc) return false;
+          std::snprintf(nm, sizeof nm, "layer%d.%d.shortcut.1", s, bi);
+          fold_scale(b, nm, c, scale_sc, pc.bias_sc, err);
+          if (!err.empty()) return false;
+        }
+        pack_conv(pc, w, scale, wsc, scale_sc);
         return true;
       };
-      if (!make(B.conv1, "conv1.weight", "bn1", bin, 9, st)) return false;
-      if (!make(B.conv2, "conv2.weight", "bn2", c, 9, 1)) return false;
-      B.has_sc = (st != 1 || bin != c);  // arch:44-45
-      if (B.has_sc && !make(B.sc, "shortcut.0.weight", "shortcut.1", bin, 1, st)) return false;
+      const bool has_sc = (st != 1 || bin != c);  // arch:44-45
+      if (!make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
+      if (!make(B.conv2, "conv2.weight", "bn2", c, 1, false)) return false;
     }
     cin = c;
     if (s >= 1) {

@@ -9,20 +9,22 @@
 namespace mlt {
 
 // fp16 weights in MFMA A-fragment order:
-//   [cout tile (cout/ct)][cin chunk (cin/kc)][tap][k-step (kc/16)][32-channel block (ct/32)][lane 64][8 halves]
+//   [cout tile (cout/ct)][cin chunk (cin/kc)][tap (taps, +1 if has_sc)][k-step (kc/16)][32-channel block (ct/32)][lane 64][8 halves]
 // lane l = 32*hh + r holds W'[cout = tile*ct + blk*32 + r][cin = chunk*kc + 16*ks + 8*hh + j][tap], j = 0..7.
+// With has_sc the block's 1x1 stride-2 projection shortcut is stored as one extra "tap" after the 9 conv taps.
 struct PackedConv {
   int cin = 0, cout = 0, taps = 0, stride = 1;
   int kc = 0, ct = 0;
+  bool has_sc = false;
   std::vector<uint16_t> w;
-  std::vector<float> bias;  // folded BN bias (zeros for the stem)
-  void *d_w = nullptr;      // device copies
-  float *d_bias = nullptr;
+  std::vector<float> bias;     // folded BN bias (zeros for the stem)
+  std::vector<float> bias_sc;  // folded BN bias of the shortcut (has_sc)
+  void *d_w = nullptr;         // device copies
+  float *d_bias = nullptr, *d_bias_sc = nullptr;
 };
 
 struct Block {
-  PackedConv conv1, conv2, sc;
-  bool has_sc = false;
+  PackedConv conv1, conv2;  // conv1 carries the projection shortcut when the block has one (arch:44-50)
 };
 
 struct Head {

@@ -43,33 +43,33 @@ def main():
 
     o = torch.from_numpy(org.astype(np.float32)); p = torch.from_numpy(pred.astype(np.float32))
     x = torch.stack([o, (o - p).abs()], 1) * np.float32(1.0 / 1023)
-    ref = F.conv2d(x, T("conv1.weight"), padding=1)
+    # the stem activation lives only in LDS (fp16); emulate that rounding
+    cur = F.conv2d(x, T("conv1.weight"), padding=1).half().float()
     idx = 0
-    got = load(idx, 32, size); idx += 1
-    print(f"{files[0]:40s} max|d| {float((got - ref).abs().max()):.3e}  (|ref|max {float(ref.abs().max()):.2f})")
-    cur = got  # feed the GPU's own (fp16-rounded) output forward so errors do not accumulate in the report
     planes = synth.STAGE_PLANES[arch]
     h = size
     for li, c in enumerate(planes):
+        last = li == len(planes) - 1
         pfx = f"layer{li}.0"
         ho = max(h // 2, 1)
         w1, b1 = fold(T(pfx + ".conv1.weight"), pfx + ".bn1")
         t_ref = F.relu(F.conv2d(cur, w1, b1, stride=2, padding=1)); t = load(idx, c, ho)
-        print(f"{files[idx]:40s} max|d| {float((t - t_ref).abs().max()):.3e}"); idx += 1
+        print(f"{files[idx]:44s} max|d| {float((t - t_ref).abs().max()):.3e}"); idx += 1
         ws, bs = fold(T(pfx + ".shortcut.0.weight"), pfx + ".shortcut.1")
-        s_ref = F.conv2d(cur, ws, bs, stride=2); s = load(idx, c, ho)
-        print(f"{files[idx]:40s} max|d| {float((s - s_ref).abs().max()):.3e}"); idx += 1
+        s_ref = F.conv2d(cur, ws, bs, stride=2); sc = load(idx, c, ho)
+        print(f"{files[idx]:44s} max|d| {float((sc - s_ref).abs().max()):.3e}"); idx += 1
         w2, b2 = fold(T(pfx + ".conv2.weight"), pfx + ".bn2")
-        b0_ref = F.relu(F.conv2d(t, w2, b2, padding=1) + s); b0 = load(idx, c, ho)
-        print(f"{files[idx]:40s} max|d| {float((b0 - b0_ref).abs().max()):.3e}"); idx += 1
+        b0_ref = F.relu(F.conv2d(t, w2, b2, padding=1) + sc); b0 = load(idx, c, ho)
+        print(f"{files[idx]:44s} max|d| {float((b0 - b0_ref).abs().max()):.3e}"); idx += 1
         pfx = f"layer{li}.1"
         w1, b1 = fold(T(pfx + ".conv1.weight"), pfx + ".bn1")
         t_ref = F.relu(F.conv2d(b0, w1, b1, padding=1)); t = load(idx, c, ho)
-        print(f"{files[idx]:40s} max|d| {float((t - t_ref).abs().max()):.3e}"); idx += 1
-        w2, b2 = fold(T(pfx + ".conv2.weight"), pfx + ".bn2")
-        o_ref = F.relu(F.conv2d(t, w2, b2, padding=1) + b0); out = load(idx, c, ho)
-        print(f"{files[idx]:40s} max|d| {float((out - o_ref).abs().max()):.3e}  (|ref|max {float(o_ref.abs().max()):.2f})"); idx += 1
-        cur = out
+        print(f"{files[idx]:44s} max|d| {float((t - t_ref).abs().max()):.3e}"); idx += 1
+        if not last:
+            w2, b2 = fold(T(pfx + ".conv2.weight"), pfx + ".bn2")
+            o_ref = F.relu(F.conv2d(t, w2, b2, padding=1) + b0); out = load(idx, c, ho)
+            print(f"{files[idx]:44s} max|d| {float((out - o_ref).abs().max()):.3e}  (|ref|max {float(o_ref.abs().max()):.2f})"); idx += 1
+            cur = out
         h = ho
     from oracle import Oracle
     ref_logits, ref_split = Oracle(blob).forward(org, pred, poc, qp)
