@@ -17,6 +17,8 @@ MLT_OK = 0
 ERR_NAMES = {1: "MLT_ERR_ARG", 2: "MLT_ERR_NO_DEVICE", 3: "MLT_ERR_WEIGHTS", 4: "MLT_ERR_SIZE_DISABLED",
              5: "MLT_ERR_HIP", 6: "MLT_ERR_NOMEM"}
 SIZE_BITS = {128: 1, 64: 2, 32: 4, 16: 8}
+FLAG_EXACT_128 = 0x1   # 128x128 in exact (fp16 hi+lo, 3-pass) arithmetic instead of fast
+FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
 EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
@@ -86,7 +88,7 @@ class MltCnn:
     """One context = one HIP device + one stream (one per encoder thread / EncCu instance)."""
 
     def __init__(self, device: int = 0, sizes=(128,), weights_dir: str | None = None, blobs: dict | None = None,
-                 head_index: dict | None = None, max_batch: int = 4096):
+                 head_index: dict | None = None, max_batch: int = 4096, flags: int = 0):
         self._lib = load_library()
         cfg = MltConfig()
         cfg.struct_size = C.sizeof(MltConfig)
@@ -96,6 +98,7 @@ class MltCnn:
         for i, s in enumerate((128, 64, 32, 16)):
             cfg.head_index[i] = (head_index or {}).get(s, -1)
         cfg.max_batch = max_batch
+        cfg.flags = flags
         self._h = C.c_void_p()
         rc = self._lib.mlt_init(C.byref(cfg), C.byref(self._h))
         if rc != MLT_OK:

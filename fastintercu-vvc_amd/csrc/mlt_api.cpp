@@ -37,7 +37,7 @@ int size_index(int size) {
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct SizeState {
-  bool enabled = false, loaded = false;
+  bool enabled = false, loaded = false, exact = false;
   int size = 0, head_index = 0;
   mlt::Model model;
 };
@@ -124,11 +124,12 @@ int gap_slots(int hw) { return hw >= 32 ? hw / 32 : 1; }
 // fp32 GAP partial sums per head.  The stem activation is never materialised (fused into layer0.0.conv1).
 size_t ws_per_cu(const mlt::Model &m, int S) {
   const int h0 = S / 2 > 0 ? S / 2 : 1;
-  size_t b = 4 * ((size_t)h0 * h0 * 32 * 2 + 256);
+  const int planes = m.exact ? 2 : 1;  // exact mode keeps a lo plane behind every activation
+  size_t b = 4 * ((size_t)h0 * h0 * 32 * 2 * planes + 256);
   int h = S;
   for (int s = 0; s < m.n_stages; ++s) {
     h = h / 2 > 0 ? h / 2 : 1;
-    b += (size_t)h * h * m.planes[s] * 2 + 256;
+    b += (size_t)h * h * m.planes[s] * 2 * planes + 256;
     if (s >= 1) b += (size_t)gap_slots(h * h) * m.planes[s] * 4 + 256;
   }
   return b + 4096;
@@ -188,6 +189,7 @@ struct ConvIO {
   const int16_t *org = nullptr, *pred = nullptr;
   long org_rs = 0, org_cs = 0, pred_rs = 0, pred_cs = 0;
   const void *stem_w = nullptr;
+  size_t x_lo = 0, y_lo = 0, res_lo = 0, ysc_lo = 0;  // exact mode: byte offsets hi plane -> lo plane
 };
 
 int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const ConvIO &io, int *hout_out) {
@@ -200,7 +202,9 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.org = io.org; a.pred = io.pred; a.org_row_stride = io.org_rs; a.org_cu_stride = io.org_cs;
   a.pred_row_stride = io.pred_rs; a.pred_cu_stride = io.pred_cs; a.stem_w = io.stem_w;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
-  const int MT = mlt_conv_tile_pixels(pc.cin, pc.cout, pc.stride, pc.taps);
+  a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
+  const int MT = pc.mt;
+  const int nsplit = pc.exact ? 2 : 1;
   int tw = hout < 32 ? hout : 32;
   int th = MT / tw < hout ? MT / tw : hout;
   int spw = MT / (tw * th);
@@ -209,7 +213,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const int ph = (th - 1) * pc.stride + halo, pw = (tw - 1) * pc.stride + halo;
   const int half = pc.stride == 2 ? (pw + 1) / 2 : 0;
   const int rp = pc.stride == 2 ? 2 * half : pw;
-  while (spw > 1 && (size_t)spw * ph * rp * PS > 64 * 1024) spw /= 2;
+  while (spw > 1 && (size_t)spw * ph * rp * PS * nsplit > 64 * 1024) spw /= 2;
   a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
   a.pw_magic = (0x100000000ull + pw - 1) / pw;
@@ -231,7 +235,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.taps, pc.has_sc, stem, a, grid_x, extra_lds, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
@@ -249,15 +253,16 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
   char *p = ctx->ws;
   auto carve = [&](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return (void *)r; };
   const int h0 = S / 2 > 0 ? S / 2 : 1;
+  const int nplanes = m.exact ? 2 : 1;
   void *pool[4];
-  for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2);
+  for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2 * nplanes);
   void *outs[5];
   float *gaps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   {
     int h = S;
     for (int s = 0; s < m.n_stages; ++s) {
       h = h / 2 > 0 ? h / 2 : 1;
-      outs[s] = carve((size_t)n * h * h * m.planes[s] * 2);
+      outs[s] = carve((size_t)n * h * h * m.planes[s] * 2 * nplanes);
       if (s >= 1) gaps[s] = (float *)carve((size_t)n * gap_slots(h * h) * m.planes[s] * 4);
     }
   }
@@ -271,8 +276,12 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
     // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
     mlt::Block &B0 = m.blocks[s][0];
+    const int ho = h / 2 > 0 ? h / 2 : 1;
+    const size_t lo_in = m.exact ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
+    const size_t lo_st = m.exact ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                      // plane bytes inside the stage
     ConvIO io;
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
+    io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
     if (s == 0) {
       io.org = d_org; io.pred = d_pred; io.org_rs = org_rs; io.org_cs = org_cs; io.pred_rs = pred_rs; io.pred_cs = pred_cs;
       io.stem_w = m.stem.d_w;
@@ -280,14 +289,17 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
     io = ConvIO();
     io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
+    io.x_lo = io.y_lo = io.res_lo = lo_st;
     if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
     // block 1 (identity shortcut)
     mlt::Block &B1 = m.blocks[s][1];
     io = ConvIO();
     io.x = pool[2]; io.y = pool[3]; io.relu = true;
+    io.x_lo = io.y_lo = lo_st;
     if ((rc = run_conv(ctx, B1.conv1, n, hout, io, &h2))) return rc;
     io = ConvIO();
     io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
+    io.x_lo = io.y_lo = io.res_lo = lo_st;
     if ((rc = run_conv(ctx, B1.conv2, n, hout, io, &h2))) return rc;
     cur = outs[s];
     h = hout;
@@ -344,7 +356,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   mlt::Model m;
   std::string err;
-  if (!mlt::build_model(blob, bytes, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  if (!mlt::build_model(blob, bytes, st.exact, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
   if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); st.loaded = false; }
   st.model = std::move(m);
@@ -378,6 +390,9 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     SizeState &st = ctx->sz[i];
     st.size = sizes[i];
     st.enabled = (mask >> i) & 1u;
+    // precision: 128 -> fast (single fp16 pass) unless MLT_FLAG_EXACT_128; 64/32/16 -> exact (fp16 hi+lo pairs, 3 passes)
+    // unless MLT_FLAG_FAST_SMALL.  See DESIGN.md "Numerics".
+    st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];

@@ -30,7 +30,11 @@ struct ConvArgs {
   long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
   const void *stem_w;          // packed stem weights (2 KiB)
   uint64_t rw_magic, rh_magic; // raw patch dims are (ph + 2) x (pw + 2)
+  // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
+  size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };
+
+struct ConvCfg { int kc, ct, mt, gt; };  // cin chunk, couts / pixels per workgroup, taps per weight step
 
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
@@ -44,8 +48,6 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, bool sc, bool stem, const ConvArgs &a, int grid_x,
-                           int extra_lds, hipStream_t st);
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
+bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);
-int mlt_conv_tile_pixels(int cin, int cout, int stride, int taps);  // output pixels per workgroup
-int mlt_conv_cout_tile(int cout);                                   // output channels per workgroup

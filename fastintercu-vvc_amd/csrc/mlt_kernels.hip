@@ -83,9 +83,13 @@ __device__ __forceinline__ float16v stem_mma(const uint32_t *raw, int ridx, int 
 //          stem activation (1 MiB per 128x128 CU) never touches HBM.
 //   gap  : fp32 per-channel partial sums of the activated output (global average pooling, arch:282).
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+//   NSPLIT = 2 ("exact" mode): every activation and weight is an fp16 (hi, lo) pair with hi + lo == the fp32
+//          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
+//          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
+//          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int KC = (CIN % 64 == 0) ? 64 : 32;
+  static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
   constexpr int NCHUNK = CIN / KC;
   constexpr int KS = KC / 16;
   constexpr int SLOTS = KC / 8;          // 16-byte slots per pixel
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   constexpr int NT = 64 * NW;
   constexpr int TT = TAPS + (SC ? 1 : 0);  // weight steps per chunk (taps + shortcut)
   constexpr int NG = TT / GT;
-  constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step
+  constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step (per split plane)
+  constexpr int NBUF = NG > 1 ? 2 : 1;          // weight ring depth
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
   static_assert(TT % GT == 0, "tap grouping");
@@ -105,8 +110,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   static_assert(!STEM || (CIN == 32 && NCHUNK == 1), "stem feeds the first 32-channel conv");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *patch = smem;
-  char *wring = smem + a.patch_bytes;
+  char *patch = smem;                                  // [NSPLIT][patch_bytes]
+  char *wring = smem + NSPLIT * a.patch_bytes;         // [NBUF][NSPLIT][WCHUNK]
+  const size_t w_lo = a.w_lo_off;                      // byte offset of the lo weight plane (NSPLIT == 2)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
     if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk's patch / weights
     if constexpr (STEM) {
       // ---- raw (org,resi) patch -> LDS, then the stem conv writes the 32-channel patch ----
-      uint32_t *raw = (uint32_t *)(wring + 2 * WCHUNK);
+      uint32_t *raw = (uint32_t *)(wring + NBUF * NSPLIT * WCHUNK);
       const int RH = PH + 2, RW = PW + 2;
       const int raw_items = (1 << spw_l) * RH * RW;
       for (int it = tid; it < raw_items; it += NT) {
@@ -186,6 +192,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       }
       const half8 a0 = *(const half8 *)((const char *)a.stem_w + lane * 16);
       const half8 a1 = *(const half8 *)((const char *)a.stem_w + 1024 + lane * 16);
+      half8 a0l, a1l;
+      if constexpr (NSPLIT == 2) {  // lo plane of the stem weights: inputs are exact integers, so 2 passes suffice
+        a0l = *(const half8 *)((const char *)a.stem_w + 2048 + lane * 16);
+        a1l = *(const half8 *)((const char *)a.stem_w + 3072 + lane * 16);
+      }
       __syncthreads();
       const int stem_px = (1 << spw_l) * PH * PW;
       for (int pb = wave; pb * 32 < stem_px; pb += NW) {
@@ -197,6 +208,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         uint32_t s = udiv_magic(r, a.ph_magic);
         int py = r - s * PH;
         float16v v = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0, a1);
+        if constexpr (NSPLIT == 2) {
+          const float16v vl = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0l, a1l);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += vl[r];
+        }
         int iy = iy0 + py, ix = ix0 + px;
         // outside the picture the conv sees ZERO padding of the stem activation, not stem(padded input)
         const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n;
@@ -205,10 +221,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
           char *dst = patch + ((s * PH + py) * RP + col) * PS + 8 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            half4 o;
+            half4 o, ol;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)v[4 * q + e] : (_Float16)0.f;
+            for (int e = 0; e < 4; ++e) {
+              o[e] = inside ? (_Float16)v[4 * q + e] : (_Float16)0.f;
+              ol[e] = (_Float16)(inside ? v[4 * q + e] - (float)o[e] : 0.f);
+            }
             *(half4 *)(dst + 16 * q) = o;
+            if constexpr (NSPLIT == 2) *(half4 *)(dst + a.patch_bytes + 16 * q) = ol;
           }
         }
       }
@@ -223,32 +243,38 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         uint32_t s = udiv_magic(r, a.ph_magic);
         int py = r - s * PH;
         int iy = iy0 + py, ix = ix0 + px;
-        half8 v;
+        half8 v, vl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        for (int e = 0; e < 8; ++e) { v[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
         if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
           const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
                                 chunk * KC + slot * 8;
           v = *(const half8 *)src;
+          if constexpr (NSPLIT == 2) vl = *(const half8 *)((const char *)src + a.x_lo_off);
         }
         int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
         *(half8 *)(patch + ((s * PH + py) * RP + col) * PS + slot * 16) = v;
+        if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + ((s * PH + py) * RP + col) * PS + slot * 16) = vl;
       }
     }
     // ---- first weight step of this chunk ----
     {
       const char *src = wsrc + (size_t)(chunk * TT) * (KS * CBT * 1024);
-      for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + pi * 1024 + lane * 16, wring + pi * 1024);
+#pragma unroll
+      for (int sp = 0; sp < NSPLIT; ++sp)
+        for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + sp * w_lo + pi * 1024 + lane * 16, wring + sp * WCHUNK + pi * 1024);
     }
     __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
 
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-      char *wcur = wring + (g & 1) * WCHUNK;
+      char *wcur = wring + (g & (NBUF - 1)) * NSPLIT * WCHUNK;
       if (g + 1 < NG) {
         const char *src = wsrc + (size_t)(chunk * TT + (g + 1) * GT) * (KS * CBT * 1024);
-        char *dst = wring + ((g + 1) & 1) * WCHUNK;
-        for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + pi * 1024 + lane * 16, dst + pi * 1024);
+        char *dst = wring + ((g + 1) & (NBUF - 1)) * NSPLIT * WCHUNK;
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp)
+          for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
       }
 #pragma unroll
       for (int tt = 0; tt < GT; ++tt) {
@@ -267,24 +293,41 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         for (int j = 0; j < WPB; ++j) bp[j] = patch + base[j] + toff;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          half8 af[WCB], bf[WPB];
+          half8 af[WCB], bf[WPB], afl[NSPLIT == 2 ? WCB : 1], bfl[NSPLIT == 2 ? WPB : 1];
 #pragma unroll
-          for (int i = 0; i < WCB; ++i)
+          for (int i = 0; i < WCB; ++i) {
             af[i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
+            if constexpr (NSPLIT == 2) afl[i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
+          }
 #pragma unroll
-          for (int j = 0; j < WPB; ++j) bf[j] = *(const half8 *)(bp[j] + ks * 32);
+          for (int j = 0; j < WPB; ++j) {
+            bf[j] = *(const half8 *)(bp[j] + ks * 32);
+            if constexpr (NSPLIT == 2) bfl[j] = *(const half8 *)(bp[j] + a.patch_bytes + ks * 32);
+          }
           if (is_sc) {
             if constexpr (SC) {
 #pragma unroll
               for (int i = 0; i < WCB; ++i)
 #pragma unroll
-                for (int j = 0; j < WPB; ++j) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc_sc[i][j], 0, 0, 0);
+                for (int j = 0; j < WPB; ++j) {
+                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc_sc[i][j], 0, 0, 0);
+                  if constexpr (NSPLIT == 2) {
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfl[j], acc_sc[i][j], 0, 0, 0);
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[i], bf[j], acc_sc[i][j], 0, 0, 0);
+                  }
+                }
             }
           } else {
 #pragma unroll
             for (int i = 0; i < WCB; ++i)
 #pragma unroll
-              for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < WPB; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if constexpr (NSPLIT == 2) {
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfl[j], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+              }
           }
         }
       }
@@ -311,24 +354,38 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
           const half4 r = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)r[e];
+          if constexpr (NSPLIT == 2) {
+            const half4 rl = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)rl[e];
+          }
         }
         if (a.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(v[4 * q + e], 0.f);
         }
         if (a.y && ok) {
-          half4 out;
+          half4 out, outl;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) out[e] = (_Float16)v[4 * q + e];
+          for (int e = 0; e < 4; ++e) {
+            out[e] = (_Float16)v[4 * q + e];
+            outl[e] = (_Float16)(v[4 * q + e] - (float)out[e]);
+          }
           *(half4 *)((_Float16 *)a.y + o + 8 * q) = out;
+          if constexpr (NSPLIT == 2) *(half4 *)((char *)((_Float16 *)a.y + o + 8 * q) + a.y_lo_off) = outl;
         }
         if constexpr (SC) {
           if (ok) {
             const float4v bs = *(const float4v *)(a.bias_sc + cbase + 8 * q);
-            half4 out;
+            half4 out, outl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) out[e] = (_Float16)(acc_sc[i][j][4 * q + e] + bs[e]);
+            for (int e = 0; e < 4; ++e) {
+              const float vs = acc_sc[i][j][4 * q + e] + bs[e];
+              out[e] = (_Float16)vs;
+              outl[e] = (_Float16)(vs - (float)out[e]);
+            }
             *(half4 *)((_Float16 *)a.y_sc + o + 8 * q) = out;
+            if constexpr (NSPLIT == 2) *(half4 *)((char *)((_Float16 *)a.y_sc + o + 8 * q) + a.ysc_lo_off) = outl;
           }
         }
       }
@@ -450,12 +507,13 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, WCB, WPB, WAVES_C, WAVES_P, GT>;
-  constexpr int KC = (CIN % 64 == 0) ? 64 : 32;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT>;
   constexpr int CBT = WCB * WAVES_C;
-  const int lds = a.patch_bytes + 2 * GT * (KC / 16) * CBT * 1024 + extra_lds;
+  constexpr int TT = TAPS + (SC ? 1 : 0);
+  constexpr int NBUF = (TT / GT) > 1 ? 2 : 1;
+  const int lds = NSPLIT * a.patch_bytes + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -468,36 +526,58 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   return hipGetLastError();
 }
 
-// wave tiling per layer shape (mlt_conv_tile_pixels / mlt_conv_cout_tile must agree)
-#define CONV_CASE(CIN, COUT, STRIDE, TAPS, SCF, STEMF, WCB, WPB, WC, WP, GT)                                  \
-  if (cin == CIN && cout == COUT && stride == STRIDE && taps == TAPS && sc == SCF && stem == STEMF)           \
-    return launch_conv_t<CIN, COUT, STRIDE, TAPS, SCF, STEMF, WCB, WPB, WC, WP, GT>(a, grid_x, extra_lds, st);
+// Per layer shape: cin chunk (KC), wave tiling and taps per weight step.  mlt_conv_cfg() is the single
+// table both the launcher and the host (packing, patch sizing) read.
+struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
+static const CfgRow kCfg[] = {
+    //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
+    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {5, 2}},     // stem-fused, + shortcut (TT = 10)
+    {32, 32, 1, {32, 32}, 1, 2, 1, 4, {9, 3}},
+    {32, 64, 2, {32, 32}, 2, 1, 1, 4, {2, 1}},
+    {64, 64, 1, {64, 32}, 2, 2, 1, 4, {1, 1}},
+    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+    {128, 128, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
+    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+    {256, 256, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
+    // CU model (planes 32/64/96/128/256)
+    {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
+    {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
+    {96, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+};
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, int taps, bool sc, bool stem, const ConvArgs &a, int grid_x,
-                           int extra_lds, hipStream_t st) {
-  //        CIN  COUT S  T  SC     STEM   WCB WPB WC WP GT
-  CONV_CASE(32, 32, 2, 9, true, true, 1, 1, 1, 4, 10)
-  CONV_CASE(32, 32, 1, 9, false, false, 1, 2, 1, 4, 9)
-  CONV_CASE(32, 64, 2, 9, true, false, 2, 1, 1, 4, 5)
-  CONV_CASE(64, 64, 1, 9, false, false, 2, 2, 1, 4, 1)
-  CONV_CASE(64, 128, 2, 9, true, false, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 128, 1, 9, false, false, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 256, 2, 9, true, false, 2, 2, 2, 2, 1)
-  CONV_CASE(256, 256, 1, 9, false, false, 2, 2, 2, 2, 1)
-  // CU model (planes 32/64/96/128/256)
-  CONV_CASE(64, 96, 2, 9, true, false, 3, 1, 1, 4, 1)
-  CONV_CASE(96, 96, 1, 9, false, false, 3, 1, 1, 4, 3)
-  CONV_CASE(96, 128, 2, 9, true, false, 2, 2, 2, 2, 2)
+bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
+  for (const CfgRow &r : kCfg)
+    if (r.cin == cin && r.cout == cout && r.stride == stride) {
+      out->kc = r.kc[exact ? 1 : 0];
+      out->ct = 32 * r.wcb * r.wc;
+      out->mt = 32 * r.wpb * r.wp;
+      out->gt = r.gt[exact ? 1 : 0];
+      return true;
+    }
+  return false;
+}
+
+#define CONV_CASE(CIN, COUT, STRIDE, SCF, STEMF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE)                                         \
+  if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                        \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCF, 1, WCB, WPB, WC, WP, GTF>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCE, 2, WCB, WPB, WC, WP, GTE>(a, grid_x, extra_lds, st);           \
+  }
+
+// stride-2 convs always carry their block's projection shortcut; the 32->32 one is also fed by the fused stem.
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, 5, 2)
+  CONV_CASE(32, 32, 1, false, false, 32, 32, 1, 2, 1, 4, 9, 3)
+  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, 2, 1)
+  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1)
+  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
+  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1)
+  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
+  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1)
+  CONV_CASE(64, 96, 2, true, false, 32, 32, 3, 1, 1, 4, 1, 1)
+  CONV_CASE(96, 96, 1, false, false, 32, 32, 3, 1, 1, 4, 3, 1)
+  CONV_CASE(96, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
   return hipErrorInvalidValue;
 }
-
-int mlt_conv_tile_pixels(int cin, int cout, int stride, int taps) {
-  (void)cin; (void)taps;
-  if (cout == 32 || cout == 64) return stride == 2 ? 128 : 256;
-  return 128;
-}
-
-int mlt_conv_cout_tile(int cout) { return cout >= 128 ? 128 : cout; }
 
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st) {
   hipLaunchKernelGGL(heads_kernel, dim3(n), dim3(256), 0, st, a);

@@ -9,7 +9,12 @@
 // sum_taps(w) to half an ulp.  Activations are spatially smooth, so the coherent part of the weight
 // rounding error (the part global average pooling cannot average away) cancels.  Every value is still
 // within one fp16 ulp of the folded fp32 weight.
+//
+// Exact mode: each folded weight is stored as an fp16 pair hi = rn(w), lo = rn(w - hi) (two planes); the
+// kernels accumulate Wh*Xh + Wh*Xl + Wl*Xh, so no diffusion is needed there.
 #include "mlt_model.h"
+
+#include "mlt_kernels.h"
 
 #include <cmath>
 #include <cstdio>
@@ -99,7 +104,19 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
                       const std::vector<double> &scale_sc) {
   const int cin = pc.cin, cout = pc.cout, taps = pc.taps, tt = taps + (w_sc ? 1 : 0);
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
-  pc.w.assign((size_t)cout * cin * tt, 0);
+  pc.plane_halves = (size_t)cout * cin * tt;
+  pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
+  auto put = [&](uint16_t &hi_slot, double exact, double &err) {
+    if (pc.exact) {
+      const uint16_t q = f32_to_f16((float)exact);
+      hi_slot = q;
+      (&hi_slot)[pc.plane_halves] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
+    } else {
+      const uint16_t q = f32_to_f16((float)(exact - err));
+      err += (double)f16_to_f32(q) - exact;
+      hi_slot = q;
+    }
+  };
   for (int co = 0; co < cout; ++co) {
     const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
     for (int ci = 0; ci < cin; ++ci) {
@@ -108,13 +125,9 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
         return pc.w[((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j];
       };
       double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of this (co, ci)
-      for (int t = 0; t < taps; ++t) {
-        const double exact = (double)w[((size_t)co * cin + ci) * taps + t] * scale[co];
-        const uint16_t q = f32_to_f16((float)(exact - err));
-        err += (double)f16_to_f32(q) - exact;
-        at(t) = q;
-      }
-      if (w_sc) at(taps) = f32_to_f16((float)((double)w_sc[(size_t)co * cin + ci] * scale_sc[co]));
+      for (int t = 0; t < taps; ++t) put(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], err);
+      double err_sc = 0.0;
+      if (w_sc) put(at(taps), (double)w_sc[(size_t)co * cin + ci] * scale_sc[co], err_sc);
     }
   }
 }
@@ -122,21 +135,29 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
 // Stem: K index k = 2*tap + channel (18 used of 32), cout = 32; the 1/1023 input scale (EncCu.cpp:836,838)
 // is folded in because the kernel feeds exact integer fp16 inputs.
 static void pack_stem(PackedConv &pc, const float *w) {
-  pc.w.assign(2 * 64 * 8, 0);
+  pc.plane_halves = 2 * 64 * 8;
+  pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
   for (int co = 0; co < 32; ++co)
     for (int c = 0; c < 2; ++c) {
       double err = 0.0;
       for (int t = 0; t < 9; ++t) {
         const double exact = (double)w[((size_t)co * 2 + c) * 9 + t] * (double)(float)(1.0 / 1023);
-        const uint16_t q = f32_to_f16((float)(exact - err));
-        err += (double)f16_to_f32(q) - exact;
         const int k = 2 * t + c, ks = k / 16, hh = (k % 16) / 8, j = k % 8;
-        pc.w[((size_t)ks * 64 + hh * 32 + co) * 8 + j] = q;
+        const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
+        if (pc.exact) {
+          const uint16_t q = f32_to_f16((float)exact);
+          pc.w[idx] = q;
+          pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
+        } else {
+          const uint16_t q = f32_to_f16((float)(exact - err));
+          err += (double)f16_to_f32(q) - exact;
+          pc.w[idx] = q;
+        }
       }
     }
 }
 
-bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
+bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::string &err) {
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
   if (std::memcmp(h->magic, "MLTW", 4) != 0 || h->version != 1 || h->arch > 1) { err = "not an MLTW v1 blob"; return false; }
@@ -152,6 +173,7 @@ bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
 
   m = Model();
   m.arch = (int)h->arch;
+  m.exact = exact;
   static const int planes_ctu[4] = {32, 64, 128, 256}, planes_cu[5] = {32, 64, 96, 128, 256};  // arch:243-256 / cu arch:63-79
   static const int cls_ctu[3] = {2, 3, 4}, cls_cu[4] = {2, 3, 4, 6};
   m.n_stages = m.arch == 0 ? 4 : 5;
@@ -162,6 +184,7 @@ bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
     const float *w = b.find("conv1.weight", 32 * 2 * 9, err);
     if (!w) return false;
     m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 9; m.stem.stride = 1; m.stem.kc = 32; m.stem.ct = 32;
+    m.stem.exact = exact;
     pack_stem(m.stem, w);
     m.stem.bias.assign(32, 0.f);
   }
@@ -174,9 +197,10 @@ bool build_model(const void *blob, size_t bytes, Model &m, std::string &err) {
       Block &B = m.blocks[s][bi];
       const int bin = bi == 0 ? cin : c, st = bi == 0 ? 2 : 1;  // _make_layer strides [2,1] (arch:265-271)
       auto make = [&](PackedConv &pc, const char *wname, const char *bnname, int ci, int stride, bool with_sc) -> bool {
-        pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc;
-        pc.kc = (ci % 64 == 0) ? 64 : 32;
-        pc.ct = c >= 128 ? 128 : c;
+        pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc; pc.exact = exact;
+        ConvCfg cfg;
+        if (!mlt_conv_cfg(ci, c, stride, exact ? 1 : 0, &cfg)) { err = "no kernel configuration for this layer shape"; return false; }
+        pc.kc = cfg.kc; pc.ct = cfg.ct; pc.mt = cfg.mt; pc.gt = cfg.gt;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, wname);
         const float *w = b.find(nm, (uint64_t)c * ci * 9, err);
         if (!w) return false;

@@ -14,8 +14,10 @@ namespace mlt {
 // With has_sc the block's 1x1 stride-2 projection shortcut is stored as one extra "tap" after the 9 conv taps.
 struct PackedConv {
   int cin = 0, cout = 0, taps = 0, stride = 1;
-  int kc = 0, ct = 0;
+  int kc = 0, ct = 0, mt = 0, gt = 0;  // from mlt_conv_cfg(): cin chunk, couts / pixels per workgroup, taps per step
   bool has_sc = false;
+  bool exact = false;          // w holds a hi plane followed by a lo plane (fp16 pair per weight)
+  size_t plane_halves = 0;     // halves per plane
   std::vector<uint16_t> w;
   std::vector<float> bias;     // folded BN bias (zeros for the stem)
   std::vector<float> bias_sc;  // folded BN bias of the shortcut (has_sc)
@@ -35,6 +37,7 @@ struct Head {
 
 struct Model {
   int arch = 0, n_stages = 0, n_heads = 0, n_logits = 0;
+  bool exact = false;
   int planes[5] = {0, 0, 0, 0, 0};
   PackedConv stem;
   Block blocks[5][2];
@@ -42,7 +45,7 @@ struct Model {
   bool on_device = false;
 };
 
-bool build_model(const void *blob, size_t bytes, Model &m, std::string &err);
+bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::string &err);
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
 

@@ -41,6 +41,14 @@ enum {
 
 #define MLT_MAX_LOGITS 15 /* CU model: 2+3+4+6; CTU (128) model: 2+3+4 = 9 */
 
+/* mlt_config.flags -- arithmetic of the conv stack (DESIGN.md "Numerics").
+ * fast : fp16 operands on the MFMA units, fp32 accumulate; |dlogit| ~ 5e-4 on ordinary inputs.
+ * exact: every weight / activation is an fp16 (hi, lo) pair, 3 MFMA passes, ~fp32 accuracy (|dlogit| ~ 1e-5).
+ * Defaults: 128x128 -> fast (it is the throughput path), 64/32/16 -> exact (few pixels per map, so
+ * fp16 rounding is not averaged away by the global pooling, and these models are 5-65x cheaper). */
+#define MLT_FLAG_EXACT_128 0x1u
+#define MLT_FLAG_FAST_SMALL 0x2u
+
 typedef struct mlt_ctx mlt_ctx;
 
 typedef struct mlt_config {
@@ -53,7 +61,7 @@ typedef struct mlt_config {
   int32_t head_index[4];  /* decision head per size {128,64,32,16}; -1 => reference default:
                              element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
   int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
-  uint32_t flags;         /* reserved, 0 */
+  uint32_t flags;         /* MLT_FLAG_* bits, 0 = defaults */
 } mlt_config;
 
 /* Create a context: selects the device, allocates workspaces, loads + folds + packs weights
