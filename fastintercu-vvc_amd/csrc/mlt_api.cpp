@@ -189,6 +189,7 @@ struct ConvIO {
   const int16_t *org = nullptr, *pred = nullptr;
   long org_rs = 0, org_cs = 0, pred_rs = 0, pred_cs = 0;
   const void *stem_w = nullptr;
+  float stem_scale = 1.f;
   size_t x_lo = 0, y_lo = 0, res_lo = 0, ysc_lo = 0;  // exact mode: byte offsets hi plane -> lo plane
 };
 
@@ -198,7 +199,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const bool stem = io.org != nullptr;
   ConvArgs a{};
   a.x = io.x; a.y = io.y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = io.res; a.n = n; a.relu = io.relu ? 1 : 0;
-  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc;
+  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale; a.stem_scale = io.stem_scale;
   a.org = io.org; a.pred = io.pred; a.org_row_stride = io.org_rs; a.org_cu_stride = io.org_cs;
   a.pred_row_stride = io.pred_rs; a.pred_cu_stride = io.pred_cs; a.stem_w = io.stem_w;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
@@ -284,7 +285,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
     if (s == 0) {
       io.org = d_org; io.pred = d_pred; io.org_rs = org_rs; io.org_cs = org_cs; io.pred_rs = pred_rs; io.pred_cs = pred_cs;
-      io.stem_w = m.stem.d_w;
+      io.stem_w = m.stem.d_w; io.stem_scale = m.stem.acc_scale;
     }
     if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
     io = ConvIO();

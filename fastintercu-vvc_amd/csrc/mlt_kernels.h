@@ -19,6 +19,8 @@ struct ConvArgs {
   uint64_t pw_magic, ph_magic; // ceil(2^32 / d)
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
+  float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
+  float stem_scale;            // STEM: stem accumulators * this = stem activation (2^-s / 1023)
   // SC variant: second output = bn(conv1x1_stride2(x)) (projection shortcut, arch:44-50)
   void *y_sc;
   const float *bias_sc;

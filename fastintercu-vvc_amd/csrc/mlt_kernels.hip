@@ -126,7 +126,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   const int hout_l = a.hout_l, hin_l = a.hin_l;
   const int Hin = 1 << hin_l;
   const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;  // tiles per row / column of one sample
-  const int mtile = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2); give every
+  // XCD a CONTIGUOUS run of tiles so that neighbouring tiles (shared halo rows, same sample) meet in one L2.
+  // Bijective for any grid size (cdna_hip_programming.md T1).
+  int mtile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    mtile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int ctile = blockIdx.y;
   const int tx = mtile & ((1 << txs_l) - 1);
   const int ty = (mtile >> txs_l) & ((1 << tys_l) - 1);
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += vl[r];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= a.stem_scale;  // 2^-s / 1023 (EncCu.cpp:836,838), exact in fp32 up to one rounding
         int iy = iy0 + py, ix = ix0 + px;
         // outside the picture the conv sees ZERO padding of the stem activation, not stem(padded input)
         const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n;
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       for (int q = 0; q < 4; ++q) {
         const float4v b = *(const float4v *)(a.bias + cbase + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + b[e];
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] * a.acc_scale + b[e];
         if (a.res && ok) {
           const half4 r = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
 #pragma unroll
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
             half4 out, outl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float vs = acc_sc[i][j][4 * q + e] + bs[e];
+              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bs[e];
               out[e] = (_Float16)vs;
               outl[e] = (_Float16)(vs - (float)out[e]);
             }

@@ -16,6 +16,7 @@
 
 #include "mlt_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -106,7 +107,18 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
   pc.plane_halves = (size_t)cout * cin * tt;
   pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
-  auto put = [&](uint16_t &hi_slot, double exact, double &err) {
+  // power-of-two storage scale: largest 2^s <= 2^6 keeping every stored weight below 2^12
+  double wmax = 1e-30;
+  for (int co = 0; co < cout; ++co) {
+    for (size_t k = 0; k < (size_t)cin * taps; ++k) wmax = std::max(wmax, std::fabs((double)w[(size_t)co * cin * taps + k] * scale[co]));
+    if (w_sc) for (int ci = 0; ci < cin; ++ci) wmax = std::max(wmax, std::fabs((double)w_sc[(size_t)co * cin + ci] * scale_sc[co]));
+  }
+  int sexp = pc.exact ? 6 : 0;
+  while (sexp > 0 && wmax * std::ldexp(1.0, sexp) >= 4096.0) --sexp;
+  const double wmul = std::ldexp(1.0, sexp);
+  pc.acc_scale = (float)std::ldexp(1.0, -sexp);
+  auto put = [&](uint16_t &hi_slot, double exact_unscaled, double &err) {
+    const double exact = exact_unscaled * wmul;
     if (pc.exact) {
       const uint16_t q = f32_to_f16((float)exact);
       hi_slot = q;
@@ -132,8 +144,9 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
   }
 }
 
-// Stem: K index k = 2*tap + channel (18 used of 32), cout = 32; the 1/1023 input scale (EncCu.cpp:836,838)
-// is folded in because the kernel feeds exact integer fp16 inputs.
+// Stem: K index k = 2*tap + channel (18 used of 32), cout = 32.  The kernel feeds exact integer fp16 inputs, so the
+// 1/1023 input scale (EncCu.cpp:836,838) is applied to the fp32 accumulator (acc_scale = 2^-s / 1023), NOT folded
+// into the fp16 weights: w/1023 ~ 1e-4 would sit in fp16's subnormal range and keep only ~10 significant bits.
 static void pack_stem(PackedConv &pc, const float *w) {
   pc.plane_halves = 2 * 64 * 8;
   pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
@@ -141,7 +154,7 @@ static void pack_stem(PackedConv &pc, const float *w) {
     for (int c = 0; c < 2; ++c) {
       double err = 0.0;
       for (int t = 0; t < 9; ++t) {
-        const double exact = (double)w[((size_t)co * 2 + c) * 9 + t] * (double)(float)(1.0 / 1023);
+        const double exact = (double)w[((size_t)co * 2 + c) * 9 + t] * 16.0;  // 2^4: |w| ~ 0.1 -> ~1.6
         const int k = 2 * t + c, ks = k / 16, hh = (k % 16) / 8, j = k % 8;
         const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
         if (pc.exact) {
@@ -185,6 +198,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::stri
     if (!w) return false;
     m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 9; m.stem.stride = 1; m.stem.kc = 32; m.stem.ct = 32;
     m.stem.exact = exact;
+    m.stem.acc_scale = (float)((double)(float)(1.0 / 1023) / 16.0);
     pack_stem(m.stem, w);
     m.stem.bias.assign(32, 0.f);
   }

@@ -18,6 +18,8 @@ struct PackedConv {
   bool has_sc = false;
   bool exact = false;          // w holds a hi plane followed by a lo plane (fp16 pair per weight)
   size_t plane_halves = 0;     // halves per plane
+  float acc_scale = 1.f;       // stored weights = folded weights * 2^s; kernels multiply accumulators by 2^-s
+                               // (keeps small weights and their lo parts out of fp16's subnormal range)
   std::vector<uint16_t> w;
   std::vector<float> bias;     // folded BN bias (zeros for the stem)
   std::vector<float> bias_sc;  // folded BN bias of the shortcut (has_sc)

@@ -44,7 +44,7 @@ def main():
     o = torch.from_numpy(org.astype(np.float32)); p = torch.from_numpy(pred.astype(np.float32))
     x = torch.stack([o, (o - p).abs()], 1) * np.float32(1.0 / 1023)
     # the stem activation lives only in LDS (fp16); emulate that rounding
-    cur = F.conv2d(x, T("conv1.weight"), padding=1).half().float()
+    cur = F.conv2d(x, T("conv1.weight"), padding=1).half().float()  # (exact-integer inputs, 1/1023 applied in fp32)
     idx = 0
     planes = synth.STAGE_PLANES[arch]
     h = size
