@@ -185,17 +185,32 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       uint32_t *raw = (uint32_t *)(wring + NBUF * NSPLIT * WCHUNK);
       const int RH = PH + 2, RW = PW + 2;
       const int raw_items = (1 << spw_l) * RH * RW;
-      for (int it = tid; it < raw_items; it += NT) {
-        uint32_t r = udiv_magic(it, a.rw_magic);
-        int rx = it - r * RW;
-        uint32_t s = udiv_magic(r, a.rh_magic);
-        int ry = r - s * RH;
-        int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-        uint32_t v = 0;
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n)
-          v = prep_pair(a.org[(size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix],
-                        a.pred[(size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix]);
-        raw[it] = v;
+      constexpr int UR = 4;
+      for (int it0 = tid; it0 < raw_items; it0 += UR * NT) {
+        int16_t vo[UR], vp[UR];
+        bool in[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+          const int it = it0 + u * NT;
+          vo[u] = 0; vp[u] = 0; in[u] = false;
+          if (it < raw_items) {
+            uint32_t r = udiv_magic(it, a.rw_magic);
+            int rx = it - r * RW;
+            uint32_t s = udiv_magic(r, a.rh_magic);
+            int ry = r - s * RH;
+            int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
+              in[u] = true;
+              vo[u] = a.org[(size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix];
+              vp[u] = a.pred[(size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+          const int it = it0 + u * NT;
+          if (it < raw_items) raw[it] = in[u] ? prep_pair(vo[u], vp[u]) : 0u;
+        }
       }
       const half8 a0 = *(const half8 *)((const char *)a.stem_w + lane * 16);
       const half8 a1 = *(const half8 *)((const char *)a.stem_w + 1024 + lane * 16);
@@ -242,28 +257,42 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         }
       }
     } else {
-      // ---- stage the input patch chunk: global (16 B / lane) -> LDS ----
+      // ---- stage the input patch chunk: global (16 B / lane) -> LDS, UN independent loads in flight per lane ----
       const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
-      for (int it = tid; it < patch_items; it += NT) {
-        int slot = it & (SLOTS - 1);
-        uint32_t pix = (uint32_t)it / SLOTS;
-        uint32_t r = udiv_magic(pix, a.pw_magic);
-        int px = pix - r * PW;
-        uint32_t s = udiv_magic(r, a.ph_magic);
-        int py = r - s * PH;
-        int iy = iy0 + py, ix = ix0 + px;
-        half8 v, vl;
+      constexpr int UN = 6;
+      for (int it0 = tid; it0 < patch_items; it0 += UN * NT) {
+        half8 v[UN], vl[UN];
+        int dst[UN];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
-          const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
-                                chunk * KC + slot * 8;
-          v = *(const half8 *)src;
-          if constexpr (NSPLIT == 2) vl = *(const half8 *)((const char *)src + a.x_lo_off);
+        for (int u = 0; u < UN; ++u) {
+          const int it = it0 + u * NT;
+          dst[u] = -1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[u][e] = (_Float16)0.f; vl[u][e] = (_Float16)0.f; }
+          if (it < patch_items) {
+            int slot = it & (SLOTS - 1);
+            uint32_t pix = (uint32_t)it / SLOTS;
+            uint32_t r = udiv_magic(pix, a.pw_magic);
+            int px = pix - r * PW;
+            uint32_t s = udiv_magic(r, a.ph_magic);
+            int py = r - s * PH;
+            int iy = iy0 + py, ix = ix0 + px;
+            int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+            dst[u] = ((s * PH + py) * RP + col) * PS + slot * 16;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
+              const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
+                                    chunk * KC + slot * 8;
+              v[u] = *(const half8 *)src;
+              if constexpr (NSPLIT == 2) vl[u] = *(const half8 *)((const char *)src + a.x_lo_off);
+            }
+          }
         }
-        int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-        *(half8 *)(patch + ((s * PH + py) * RP + col) * PS + slot * 16) = v;
-        if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + ((s * PH + py) * RP + col) * PS + slot * 16) = vl;
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (dst[u] >= 0) {
+            *(half8 *)(patch + dst[u]) = v[u];
+            if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst[u]) = vl[u];
+          }
       }
     }
     // ---- first weight step of this chunk ----
@@ -346,9 +375,38 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
 
   // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
+  // residual reads first, all of them, so they are in flight together (and never queue behind the stores)
+  half4 resv[WCB][WPB][4], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][4];
+  if (a.res) {
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (opix[j] >= 0) {
+            resv[i][j][q] = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
+            if constexpr (NSPLIT == 2) resl[i][j][q] = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              resv[i][j][q][e] = (_Float16)0.f;
+              if constexpr (NSPLIT == 2) resl[i][j][q][e] = (_Float16)0.f;
+            }
+          }
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
     const int cbase = ctile * CT + (wc * WCB + i) * 32 + 4 * h;
+    float4v bq[4], bsq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bq[q] = *(const float4v *)(a.bias + cbase + 8 * q);
+      if constexpr (SC) bsq[q] = *(const float4v *)(a.bias_sc + cbase + 8 * q);
+    }
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
       const bool ok = opix[j] >= 0;
@@ -356,17 +414,13 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       float v[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4v b = *(const float4v *)(a.bias + cbase + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] * a.acc_scale + b[e];
-        if (a.res && ok) {
-          const half4 r = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] * a.acc_scale + bq[q][e];
+        if (a.res) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)r[e];
-          if constexpr (NSPLIT == 2) {
-            const half4 rl = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)rl[e];
+          for (int e = 0; e < 4; ++e) {
+            v[4 * q + e] += (float)resv[i][j][q][e];
+            if constexpr (NSPLIT == 2) v[4 * q + e] += (float)resl[i][j][q][e];
           }
         }
         if (a.relu) {
@@ -385,11 +439,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         }
         if constexpr (SC) {
           if (ok) {
-            const float4v bs = *(const float4v *)(a.bias_sc + cbase + 8 * q);
             half4 out, outl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bs[e];
+              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[q][e];
               out[e] = (_Float16)vs;
               outl[e] = (_Float16)(vs - (float)out[e]);
             }
