@@ -212,15 +212,17 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const int halo = pc.taps == 9 ? 3 : 1;
   const int PS = pc.kc * 2 + 16;
   const int ph = (th - 1) * pc.stride + halo, pw = (tw - 1) * pc.stride + halo;
-  const int half = pc.stride == 2 ? (pw + 1) / 2 : 0;
-  const int rp = pc.stride == 2 ? 2 * half : pw;
+  // row pitch (pixels): stride 2 keeps even / odd columns in two halves; 8-wide maps need RP = 2 (mod 4) so that the
+  // two rows a ds_read_b128 lane group reads sit 8 (mod 16) pixels apart (mlt_kernels.hip, lane ranking)
+  int half = pc.stride == 2 ? (pw + 1) / 2 : 0;
+  if (pc.stride == 2 && tw == 8 && (2 * half) % 4 != 2) ++half;
+  int rp = pc.stride == 2 ? 2 * half : pw;
+  if (pc.stride == 1 && tw == 8) while (rp % 4 != 2) ++rp;
   while (spw > 1 && (size_t)spw * ph * rp * PS * nsplit > 64 * 1024) spw /= 2;
   a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
-  a.pw_magic = (0x100000000ull + pw - 1) / pw;
-  a.ph_magic = (0x100000000ull + ph - 1) / ph;
-  a.rw_magic = (0x100000000ull + pw + 1) / (pw + 2);
-  a.rh_magic = (0x100000000ull + ph + 1) / (ph + 2);
+  auto magic = [](int d) { return (uint32_t)((0x100000000ull + d - 1) / d); };  // d >= 2 (ph, pw >= 3)
+  a.pw_magic = magic(pw); a.ph_magic = magic(ph); a.rw_magic = magic(pw + 2); a.rh_magic = magic(ph + 2);
   a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
   const int extra_lds = stem ? (spw * (ph + 2) * (pw + 2) * 4 + 15) / 16 * 16 : 0;
   const int hw = hout * hout;

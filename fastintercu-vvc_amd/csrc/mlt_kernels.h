@@ -16,7 +16,7 @@ struct ConvArgs {
   int hin_l, hout_l;           // log2 of input / output height (= width)
   int tw_l, th_l, spw_l;       // log2 of tile width, tile height, samples per workgroup
   int ph, pw, rp, half;        // patch rows, cols, row pitch (pixels), parity-split half width
-  uint64_t pw_magic, ph_magic; // ceil(2^32 / d)
+  uint32_t pw_magic, ph_magic; // ceil(2^32 / d), d >= 2
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
   float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
@@ -31,7 +31,7 @@ struct ConvArgs {
   const int16_t *org, *pred;
   long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
   const void *stem_w;          // packed stem weights (2 KiB)
-  uint64_t rw_magic, rh_magic; // raw patch dims are (ph + 2) x (pw + 2)
+  uint32_t rw_magic, rh_magic; // raw patch dims are (ph + 2) x (pw + 2)
   // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };

@@ -33,7 +33,8 @@ __device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_bas
   __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc_lane), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
-__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint64_t magic) { return (uint32_t)(((uint64_t)n * magic) >> 32); }
+// n / d for d >= 2 with magic = ceil(2^32 / d); exact while n * d < 2^32 (patch indices are < 2^16)
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
 
 // (org, |org - pred|) as an exact-integer fp16 pair: EncCu.cpp:816,827 (u16 cast), :833 (absdiff),
 // :848-867 (clip to [0,1] after the 1/1023 scale == clip the integer to [0,1023]; the scale itself
@@ -87,7 +88,7 @@ __device__ __forceinline__ float16v stem_mma(const uint32_t *raw, int ridx, int 
 //          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
 //          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
 //          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
   constexpr int NCHUNK = CIN / KC;
@@ -101,13 +102,17 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   constexpr int TT = TAPS + (SC ? 1 : 0);  // weight steps per chunk (taps + shortcut)
   constexpr int NG = TT / GT;
   constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step (per split plane)
-  constexpr int NBUF = NG > 1 ? 2 : 1;          // weight ring depth
+  constexpr int NBUF = NG > 1 ? RB : 1;         // weight ring depth; steps are prefetched NBUF-1 ahead
+  constexpr int PFD = NBUF > 1 ? NBUF - 1 : 0;  // prefetch distance (steps)
+  constexpr int NPIECE = WCHUNK / 1024;                       // 1 KiB LDS-DMA pieces per step and plane
+  constexpr int PPW = NSPLIT * ((NPIECE + NW - 1) / NW);      // LDS-DMA instructions EVERY wave issues per step
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
   static_assert(TT % GT == 0, "tap grouping");
   static_assert(COUT % CT == 0, "cout tiling");
   static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
   static_assert(!STEM || (CIN == 32 && NCHUNK == 1), "stem feeds the first 32-channel conv");
+  static_assert(RB >= 1 && RB <= 4, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *patch = smem;                                  // [NSPLIT][patch_bytes]
@@ -145,12 +150,29 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   int base[WPB];      // LDS byte offset of (pixel, tap (0,0), slot h)
   int opix[WPB];      // output pixel index (flattened n,y,x) or -1
   int gidx[WPB];      // gap partial-sum row (sample * nslots + slot) or -1
+  // ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32 for the upper half,
+  // MI355X_MICROARCH.md LDS table).  With PS/16 odd a group is conflict-free iff its 16 patch-pixel indices are
+  // distinct mod 16, so lanes are RANKED such that each group owns 16 consecutive logical pixels: one 16-pixel row
+  // segment (TW >= 16) or, for 8-wide maps, two 8-pixel rows 4/STRIDE apart (their patch rows are then
+  // 4 * RP = 8 (mod 16) pixels apart because the host keeps RP = 2 (mod 4)).  Only used when a 32-pixel block lies
+  // inside one sample (H*W >= 32); smaller maps keep the natural order the GAP butterfly relies on.
+  const bool rank_lanes = (tw_l + th_l) >= 5;
+  int pr = p;
+  if (rank_lanes) pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
+  const bool pair_rows = rank_lanes && tw_l == 3 && th_l >= 3;
 #pragma unroll
   for (int j = 0; j < WPB; ++j) {
-    int m = (wp * WPB + j) * 32 + p;
+    int m = (wp * WPB + j) * 32 + pr;
     bool ok = m < m_valid;
     int mm = ok ? m : 0;
-    int x = mm & (TW - 1), y = (mm >> tw_l) & (TH - 1), s = mm >> (tw_l + th_l);
+    int x = mm & (TW - 1);
+    int q = mm >> tw_l;  // row counter over (sample, y)
+    if (pair_rows) {
+      const int k = q & 7;
+      const int kp = STRIDE == 1 ? (((k & 1) << 2) | (k >> 1)) : ((k & 4) | ((k & 1) << 1) | ((k >> 1) & 1));
+      q = (q & ~7) | kp;
+    }
+    int y = q & (TH - 1), s = q >> th_l;
     base[j] = ((s * PH + y * STRIDE) * RP + x) * PS + h * 16;
     int oy = (ty << th_l) + y, ox = (tx << tw_l) + x;
     ok = ok && (n0 + s) < a.n;
@@ -186,30 +208,31 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       const int RH = PH + 2, RW = PW + 2;
       const int raw_items = (1 << spw_l) * RH * RW;
       constexpr int UR = 4;
-      for (int it0 = tid; it0 < raw_items; it0 += UR * NT) {
-        int16_t vo[UR], vp[UR];
-        bool in[UR];
+      {
+        // item = raw pixel; (rr, rx) advance by NT pixels per step with one carry (no per-item division)
+        const int step_r = udiv_magic(NT, a.rw_magic), step_x = NT - step_r * RW;
+        int rr = udiv_magic(tid, a.rw_magic), rx = tid - rr * RW;
+        for (int it0 = tid; it0 < raw_items; it0 += UR * NT) {
+          int16_t vo[UR], vp[UR];
+          bool in[UR];
 #pragma unroll
-        for (int u = 0; u < UR; ++u) {
-          const int it = it0 + u * NT;
-          vo[u] = 0; vp[u] = 0; in[u] = false;
-          if (it < raw_items) {
-            uint32_t r = udiv_magic(it, a.rw_magic);
-            int rx = it - r * RW;
-            uint32_t s = udiv_magic(r, a.rh_magic);
-            int ry = r - s * RH;
-            int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
-              in[u] = true;
-              vo[u] = a.org[(size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix];
-              vp[u] = a.pred[(size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix];
-            }
+          for (int u = 0; u < UR; ++u) {
+            const int it = it0 + u * NT;
+            const int s = udiv_magic(rr, a.rh_magic), ry = rr - s * RH;
+            const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+            in[u] = it < raw_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+            const size_t oo = in[u] ? (size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : 0;
+            const size_t po = in[u] ? (size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : 0;
+            vo[u] = a.org[oo];   // branch-free (clamped address), see the patch staging below
+            vp[u] = a.pred[po];
+            rx += step_x; rr += step_r;
+            if (rx >= RW) { rx -= RW; ++rr; }
           }
-        }
 #pragma unroll
-        for (int u = 0; u < UR; ++u) {
-          const int it = it0 + u * NT;
-          if (it < raw_items) raw[it] = in[u] ? prep_pair(vo[u], vp[u]) : 0u;
+          for (int u = 0; u < UR; ++u) {
+            const int it = it0 + u * NT;
+            if (it < raw_items) raw[it] = in[u] ? prep_pair(vo[u], vp[u]) : 0u;
+          }
         }
       }
       const half8 a0 = *(const half8 *)((const char *)a.stem_w + lane * 16);
@@ -221,14 +244,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       }
       __syncthreads();
       const int stem_px = (1 << spw_l) * PH * PW;
+      const int sstep_r = udiv_magic(32 * NW, a.pw_magic), sstep_x = 32 * NW - sstep_r * PW;
+      int sr = udiv_magic(wave * 32 + p, a.pw_magic), sx = wave * 32 + p - sr * PW;
       for (int pb = wave; pb * 32 < stem_px; pb += NW) {
-        int m = pb * 32 + p;
-        bool ok = m < stem_px;
-        int mm = ok ? m : 0;
-        uint32_t r = udiv_magic(mm, a.pw_magic);
-        int px = mm - r * PW;
-        uint32_t s = udiv_magic(r, a.ph_magic);
-        int py = r - s * PH;
+        const bool ok = pb * 32 + p < stem_px;
+        const int rcl = ok ? sr : 0, px = ok ? sx : 0;
+        const int s = udiv_magic(rcl, a.ph_magic), py = rcl - s * PH;
+        sx += sstep_x; sr += sstep_r;
+        if (sx >= PW) { sx -= PW; ++sr; }
         float16v v = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0, a1);
         if constexpr (NSPLIT == 2) {
           const float16v vl = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0l, a1l);
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
         for (int r = 0; r < 16; ++r) v[r] *= a.stem_scale;  // 2^-s / 1023 (EncCu.cpp:836,838), exact in fp32 up to one rounding
         int iy = iy0 + py, ix = ix0 + px;
         // outside the picture the conv sees ZERO padding of the stem activation, not stem(padded input)
-        const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n;
+        const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
         if (ok) {
           int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
           char *dst = patch + ((s * PH + py) * RP + col) * PS + 8 * h;
@@ -260,59 +283,82 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       // ---- stage the input patch chunk: global (16 B / lane) -> LDS, UN independent loads in flight per lane ----
       const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
       constexpr int UN = 6;
+      constexpr int PSTEP = NT / SLOTS;  // pixels advanced per item step; the 16-byte slot of a lane is fixed
+      const int slot = tid & (SLOTS - 1);
+      const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
+      int rr = udiv_magic(tid / SLOTS, a.pw_magic), px = tid / SLOTS - rr * PW;  // rr = row counter over (sample, py)
       for (int it0 = tid; it0 < patch_items; it0 += UN * NT) {
+        // Branch-free: every load is issued (from a clamped, always-valid address) before any result is used, so
+        // UN loads per lane are in flight together; a conditional load would be waited for inside its branch.
         half8 v[UN], vl[UN];
         int dst[UN];
+        bool live[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           const int it = it0 + u * NT;
-          dst[u] = -1;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { v[u][e] = (_Float16)0.f; vl[u][e] = (_Float16)0.f; }
-          if (it < patch_items) {
-            int slot = it & (SLOTS - 1);
-            uint32_t pix = (uint32_t)it / SLOTS;
-            uint32_t r = udiv_magic(pix, a.pw_magic);
-            int px = pix - r * PW;
-            uint32_t s = udiv_magic(r, a.ph_magic);
-            int py = r - s * PH;
-            int iy = iy0 + py, ix = ix0 + px;
-            int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-            dst[u] = ((s * PH + py) * RP + col) * PS + slot * 16;
-            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (int)(n0 + s) < a.n) {
-              const _Float16 *src = (const _Float16 *)a.x + ((((size_t)(n0 + s) << hin_l) + iy) << hin_l) * CIN + (size_t)ix * CIN +
-                                    chunk * KC + slot * 8;
-              v[u] = *(const half8 *)src;
-              if constexpr (NSPLIT == 2) vl[u] = *(const half8 *)((const char *)src + a.x_lo_off);
-            }
-          }
+          const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
+          const int iy = iy0 + py, ix = ix0 + px;
+          const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+          dst[u] = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
+          live[u] = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+          const size_t off = live[u] ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : 0;
+          v[u] = *(const half8 *)((const _Float16 *)a.x + off);
+          if constexpr (NSPLIT == 2) vl[u] = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
+          px += step_x; rr += step_r;
+          if (px >= PW) { px -= PW; ++rr; }
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
+        for (int u = 0; u < UN; ++u) {
+          if (!live[u]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[u][e] = (_Float16)0.f; if constexpr (NSPLIT == 2) vl[u][e] = (_Float16)0.f; }
+          }
           if (dst[u] >= 0) {
             *(half8 *)(patch + dst[u]) = v[u];
             if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst[u]) = vl[u];
           }
+        }
       }
     }
-    // ---- first weight step of this chunk ----
-    {
-      const char *src = wsrc + (size_t)(chunk * TT) * (KS * CBT * 1024);
+    // ---- weight ring: steps 0..PFD-1 of this chunk (or the only step) ----
+    auto issue_step = [&](int g, int buf) {
+      const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
+      char *dst = wring + buf * NSPLIT * WCHUNK;
+      // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
+      // its own re-copies the last piece (same bytes to the same place: benign)
 #pragma unroll
       for (int sp = 0; sp < NSPLIT; ++sp)
-        for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + sp * w_lo + pi * 1024 + lane * 16, wring + sp * WCHUNK + pi * 1024);
+#pragma unroll
+        for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
+          int pi = wave + k * NW;
+          pi = pi < NPIECE ? pi : NPIECE - 1;
+          glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
+        }
+    };
+    issue_step(0, 0);
+    if constexpr (NBUF > 1) {
+#pragma unroll
+      for (int d = 1; d < PFD; ++d)
+        if (d < NG) issue_step(d, d);
+      // step 0 must have landed; the PFD-1 younger steps may stay in flight.  LDS-DMA data is ordered for another
+      // wave's ds_read only by the ISSUING wave's vmcnt followed by a barrier; the patch ds_writes need lgkmcnt(0).
+      constexpr int INFL0 = (PFD - 1 < NG - 1 ? PFD - 1 : NG - 1) * PPW;
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL0) : "memory");
+    } else {
+      __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
     }
-    __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
 
+    int cur_buf = 0;
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-      char *wcur = wring + (g & (NBUF - 1)) * NSPLIT * WCHUNK;
-      if (g + 1 < NG) {
-        const char *src = wsrc + (size_t)(chunk * TT + (g + 1) * GT) * (KS * CBT * 1024);
-        char *dst = wring + ((g + 1) & (NBUF - 1)) * NSPLIT * WCHUNK;
-#pragma unroll
-        for (int sp = 0; sp < NSPLIT; ++sp)
-          for (int pi = wave; pi < WCHUNK / 1024; pi += NW) glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
+      char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
+      if constexpr (NBUF > 1) {
+        // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
+        if (g + PFD < NG) {
+          int nb = cur_buf + PFD;
+          if (nb >= NBUF) nb -= NBUF;
+          issue_step(g + PFD, nb);
+        }
       }
 #pragma unroll
       for (int tt = 0; tt < GT; ++tt) {
@@ -369,7 +415,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
           }
         }
       }
-      if (g + 1 < NG) __syncthreads();  // next weights landed (vmcnt(0)) + everyone finished this buffer
+      if constexpr (NBUF > 1) {
+        if (g + 1 < NG) {
+          // step g+1 must have landed; steps g+2 .. min(g+PFD, NG-1) may stay in flight (counted vmcnt, raw barrier:
+          // __syncthreads() would drain the LDS-DMA queue with vmcnt(0))
+          const int last = g + PFD < NG - 1 ? g + PFD : NG - 1;
+          const int infl = last - (g + 1);
+          if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+          else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          if (++cur_buf == NBUF) cur_buf = 0;
+        }
+      }
     }
   }
 
@@ -384,17 +441,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       for (int j = 0; j < WPB; ++j) {
         const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 4 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (opix[j] >= 0) {
-            resv[i][j][q] = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
-            if constexpr (NSPLIT == 2) resl[i][j][q] = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              resv[i][j][q][e] = (_Float16)0.f;
-              if constexpr (NSPLIT == 2) resl[i][j][q][e] = (_Float16)0.f;
-            }
-          }
+        for (int q = 0; q < 4; ++q) {  // clamped address (o = channel offset only when the pixel is invalid): branch-free
+          resv[i][j][q] = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
+          if constexpr (NSPLIT == 2) resl[i][j][q] = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
         }
       }
   }
@@ -569,12 +618,12 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
-  constexpr int NBUF = (TT / GT) > 1 ? 2 : 1;
+  constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
   const int lds = NSPLIT * a.patch_bytes + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
   static bool configured = false;
   if (!configured) {
@@ -593,13 +642,13 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
-    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {5, 2}},     // stem-fused, + shortcut (TT = 10)
-    {32, 32, 1, {32, 32}, 1, 2, 1, 4, {9, 3}},
+    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {2, 2}},     // stem-fused, + shortcut (TT = 10)
+    {32, 32, 1, {32, 32}, 1, 2, 1, 8, {9, 3}},
     {32, 64, 2, {32, 32}, 2, 1, 1, 4, {2, 1}},
     {64, 64, 1, {64, 32}, 2, 2, 1, 4, {1, 1}},
-    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {1, 1}},
     {128, 128, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
-    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {1, 1}},
     {256, 256, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
@@ -619,25 +668,26 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   return false;
 }
 
-#define CONV_CASE(CIN, COUT, STRIDE, SCF, STEMF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE)                                         \
-  if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                        \
-    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCF, 1, WCB, WPB, WC, WP, GTF>(a, grid_x, extra_lds, st); \
-    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCE, 2, WCB, WPB, WC, WP, GTE>(a, grid_x, extra_lds, st);           \
+// RBF / RBE: weight-ring depth (fast / exact).  Must mirror kCfg.
+#define CONV_CASE(CIN, COUT, STRIDE, SCF, STEMF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE)                                    \
+  if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE>(a, grid_x, extra_lds, st);           \
   }
 
 // stride-2 convs always carry their block's projection shortcut; the 32->32 one is also fed by the fused stem.
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, 5, 2)
-  CONV_CASE(32, 32, 1, false, false, 32, 32, 1, 2, 1, 4, 9, 3)
-  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, 2, 1)
-  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1)
-  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
-  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1)
-  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
-  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1)
-  CONV_CASE(64, 96, 2, true, false, 32, 32, 3, 1, 1, 4, 1, 1)
-  CONV_CASE(96, 96, 1, false, false, 32, 32, 3, 1, 1, 4, 3, 1)
-  CONV_CASE(96, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1)
+  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, 2, 2, 3, 2)
+  CONV_CASE(32, 32, 1, false, false, 32, 32, 1, 2, 1, 8, 9, 3, 1, 2)
+  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, 2, 1, 3, 2)
+  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1, 3, 2)
+  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 1, 1, 4, 2)
+  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, 3, 2)
+  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 1, 1, 3, 2)
+  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, 3, 2)
+  CONV_CASE(64, 96, 2, true, false, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
+  CONV_CASE(96, 96, 1, false, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
+  CONV_CASE(96, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
   return hipErrorInvalidValue;
 }
 
