@@ -29,11 +29,13 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """Cross-compiles without a GPU (hipcc only needs the gfx950 target)."""
-    if force or stale():
-        cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+def build_lib(force: bool = False, verbose: bool = False, defines=(), out: str | None = None) -> str:
+    """Cross-compiles without a GPU (hipcc only needs the gfx950 target).
+    `defines` / `out`: tuning variants (scripts/sweep_cfg.py); the product is always LIB with no defines."""
+    target = out or LIB
+    if force or out or stale():
+        cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", target]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return target

@@ -45,7 +45,7 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    return os.environ.get("MLT_LIB_PATH") or _build.LIB  # MLT_LIB_PATH: tuning variants only (scripts/sweep_cfg.py)
 
 
 def load_library():

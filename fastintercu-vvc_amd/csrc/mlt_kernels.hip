@@ -221,8 +221,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
             const int s = udiv_magic(rr, a.rh_magic), ry = rr - s * RH;
             const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
             in[u] = it < raw_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-            const size_t oo = in[u] ? (size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : 0;
-            const size_t po = in[u] ? (size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : 0;
+            // masked lanes read a valid, per-lane / per-workgroup distinct element (never one shared hot line)
+            const size_t oo = in[u] ? (size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n0 * a.org_cu_stride + (tid & (Hin - 1));
+            const size_t po = in[u] ? (size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n0 * a.pred_cu_stride + (tid & (Hin - 1));
             vo[u] = a.org[oo];   // branch-free (clamped address), see the patch staging below
             vp[u] = a.pred[po];
             rx += step_x; rr += step_r;
@@ -282,7 +283,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
     } else {
       // ---- stage the input patch chunk: global (16 B / lane) -> LDS, UN independent loads in flight per lane ----
       const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
-      constexpr int UN = 6;
+      constexpr int UN = (STRIDE == 2 ? 10 : 6) / NSPLIT;  // loads in flight per lane: one round trip for the usual patch
+      // masked lanes (halo outside the picture, loop tail) still load -- from a valid address that is DISTINCT per lane
+      // and per workgroup (inside this tile's first sample), never from one shared location (that would hot-spot a line)
+      const size_t safe_off = ((((size_t)n0 << hin_l) << hin_l) * CIN) + (size_t)((tid * 8) & ((CIN << (2 * hin_l)) - 1) & ~7);
       constexpr int PSTEP = NT / SLOTS;  // pixels advanced per item step; the 16-byte slot of a lane is fixed
       const int slot = tid & (SLOTS - 1);
       const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
           const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
           dst[u] = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
           live[u] = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-          const size_t off = live[u] ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : 0;
+          const size_t off = live[u] ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : safe_off;
           v[u] = *(const half8 *)((const _Float16 *)a.x + off);
           if constexpr (NSPLIT == 2) vl[u] = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
           px += step_x; rr += step_r;
@@ -360,59 +364,60 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
           issue_step(g + PFD, nb);
         }
       }
-#pragma unroll
-      for (int tt = 0; tt < GT; ++tt) {
+      // Fragment reads run ONE (tap, k-step) ahead of the MFMAs that consume them (register double buffer), so the
+      // ds_read latency of item i+1 hides under the MFMAs of item i instead of serialising read -> wait -> MFMA.
+      auto tap_off = [&](int tt) -> int {
         const int t = g * GT + tt;
-        const bool is_sc = SC && t == TAPS;
-        int toff;
-        if (TAPS == 9) {
-          const int te = is_sc ? 4 : t;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
-          int dy = te / 3, dx = te - dy * 3;
-          toff = STRIDE == 2 ? (dy * RP + (dx & 1) * HALF + (dx >> 1)) * PS : (dy * RP + dx) * PS;
-        } else {
-          toff = 0;
+        if (TAPS != 9) return 0;
+        const int te = (SC && t == TAPS) ? 4 : t;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+        const int dy = te / 3, dx = te - dy * 3;
+        return STRIDE == 2 ? (dy * RP + (dx & 1) * HALF + (dx >> 1)) * PS : (dy * RP + dx) * PS;
+      };
+      half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
+      auto load_frags = [&](int item, int slot) {
+        const int tt = item / KS, ks = item - tt * KS;
+        const int toff = tap_off(tt);
+#pragma unroll
+        for (int i = 0; i < WCB; ++i) {
+          af[slot][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
+          if constexpr (NSPLIT == 2) afl[slot][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
         }
-        const char *bp[WPB];
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) bp[j] = patch + base[j] + toff;
+        for (int j = 0; j < WPB; ++j) {
+          bf[slot][j] = *(const half8 *)(patch + base[j] + toff + ks * 32);
+          if constexpr (NSPLIT == 2) bfl[slot][j] = *(const half8 *)(patch + a.patch_bytes + base[j] + toff + ks * 32);
+        }
+      };
+      load_frags(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          half8 af[WCB], bf[WPB], afl[NSPLIT == 2 ? WCB : 1], bfl[NSPLIT == 2 ? WPB : 1];
-#pragma unroll
-          for (int i = 0; i < WCB; ++i) {
-            af[i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
-            if constexpr (NSPLIT == 2) afl[i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
-          }
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            bf[j] = *(const half8 *)(bp[j] + ks * 32);
-            if constexpr (NSPLIT == 2) bfl[j] = *(const half8 *)(bp[j] + a.patch_bytes + ks * 32);
-          }
-          if (is_sc) {
-            if constexpr (SC) {
-#pragma unroll
-              for (int i = 0; i < WCB; ++i)
-#pragma unroll
-                for (int j = 0; j < WPB; ++j) {
-                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc_sc[i][j], 0, 0, 0);
-                  if constexpr (NSPLIT == 2) {
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfl[j], acc_sc[i][j], 0, 0, 0);
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[i], bf[j], acc_sc[i][j], 0, 0, 0);
-                  }
-                }
-            }
-          } else {
+      for (int item = 0; item < GT * KS; ++item) {
+        const int cur = item & 1;
+        if (item + 1 < GT * KS) load_frags(item + 1, cur ^ 1);
+        const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+        if (is_sc) {
+          if constexpr (SC) {
 #pragma unroll
             for (int i = 0; i < WCB; ++i)
 #pragma unroll
               for (int j = 0; j < WPB; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
                 if constexpr (NSPLIT == 2) {
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfl[j], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[i], bf[j], acc[i][j], 0, 0, 0);
+                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
+                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
                 }
               }
           }
+        } else {
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+              if constexpr (NSPLIT == 2) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+              }
+            }
         }
       }
       if constexpr (NBUF > 1) {
@@ -639,16 +644,32 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 
 // Per layer shape: cin chunk (KC), wave tiling and taps per weight step.  mlt_conv_cfg() is the single
 // table both the launcher and the host (packing, patch sizing) read.
+// build-time tuning knobs (scripts/sweep_cfg.py): taps per weight step / ring depth of selected kernels
+#ifndef CFG_STEM_GT
+#define CFG_STEM_GT 10
+#endif
+#ifndef CFG_STEM_RB
+#define CFG_STEM_RB 1
+#endif
+#ifndef CFG_3264_GT
+#define CFG_3264_GT 10
+#endif
+#ifndef CFG_3264_RB
+#define CFG_3264_RB 1
+#endif
+#ifndef CFG_S1_RB
+#define CFG_S1_RB 2
+#endif
 struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
-    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {2, 2}},     // stem-fused, + shortcut (TT = 10)
+    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {CFG_STEM_GT, 2}},     // stem-fused, + shortcut (TT = 10)
     {32, 32, 1, {32, 32}, 1, 2, 1, 8, {9, 3}},
-    {32, 64, 2, {32, 32}, 2, 1, 1, 4, {2, 1}},
+    {32, 64, 2, {32, 32}, 2, 1, 1, 4, {CFG_3264_GT, 1}},
     {64, 64, 1, {64, 32}, 2, 2, 1, 4, {1, 1}},
-    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {1, 1}},
+    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
     {128, 128, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
-    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {1, 1}},
+    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
     {256, 256, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
@@ -677,14 +698,14 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 
 // stride-2 convs always carry their block's projection shortcut; the 32->32 one is also fed by the fused stem.
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, 2, 2, 3, 2)
+  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, CFG_STEM_GT, 2, CFG_STEM_RB, 2)
   CONV_CASE(32, 32, 1, false, false, 32, 32, 1, 2, 1, 8, 9, 3, 1, 2)
-  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, 2, 1, 3, 2)
-  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1, 3, 2)
-  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 1, 1, 4, 2)
-  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, 3, 2)
-  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 1, 1, 3, 2)
-  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, 3, 2)
+  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
+  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
   CONV_CASE(64, 96, 2, true, false, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
   CONV_CASE(96, 96, 1, false, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
   CONV_CASE(96, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Build-time tuning sweep: `build` (CPU box) compiles variant libraries under gpurun_out-independent
+`fastintercu-vvc_amd/_variants/`; `run` (GPU box) benches each one and prints per-kernel ms."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
+VARIANTS = {
+    "base": [],
+    "3264_gt2_rb3": ["CFG_3264_GT=2", "CFG_3264_RB=3"],
+    "3264_gt5_rb2": ["CFG_3264_GT=5", "CFG_3264_RB=2"],
+    "3264_gt10": ["CFG_3264_GT=10", "CFG_3264_RB=1"],
+    "stem_gt2_rb2": ["CFG_STEM_GT=2", "CFG_STEM_RB=2"],
+    "stem_gt5_rb2": ["CFG_STEM_GT=5", "CFG_STEM_RB=2"],
+    "stem_gt10": ["CFG_STEM_GT=10", "CFG_STEM_RB=1"],
+    "s1_rb2": ["CFG_S1_RB=2"],
+    "s1_rb4": ["CFG_S1_RB=4"],
+}
+
+
+def main():
+    import mltcnn_pkg
+    pkg = mltcnn_pkg.load()
+    if sys.argv[1] == "build":
+        os.makedirs(VDIR, exist_ok=True)
+        for name, defs in VARIANTS.items():
+            pkg.build.build_lib(defines=defs, out=os.path.join(VDIR, f"lib_{name}.so"))
+            print("built", name)
+    else:
+        for name in VARIANTS:
+            env = dict(os.environ, MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                                 env=env, capture_output=True, text=True).stdout
+            line = [l for l in out.splitlines() if l.startswith("{")]
+            if not line:
+                print(name, "FAILED")
+                continue
+            d = json.loads(line[-1])
+            print(f"{name:16s} {d['value']:10.0f} CU/s  err {d['parity']['max_abs_dlogit']:.1e}  " +
+                  " ".join(f"{k['avg_ms']:.3f}" for k in d["derived"]["kernels"]))
+
+
+if __name__ == "__main__":
+    main()
