@@ -76,6 +76,7 @@ namespace {
 
 int upload_model(mlt_ctx *ctx, mlt::Model &m) {
   auto up = [&](mlt::PackedConv &pc) -> int {
+    if (pc.w.empty()) return MLT_OK;  // layer0.0.conv1: folded into the composed first layer
     HIP_TRY(ctx, hipMalloc(&pc.d_w, pc.w.size() * 2));
     HIP_TRY(ctx, hipMemcpy(pc.d_w, pc.w.data(), pc.w.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc((void **)&pc.d_bias, pc.bias.size() * 4));
@@ -185,23 +186,15 @@ struct ConvIO {
   const void *res = nullptr;  // residual added before the ReLU
   float *gap = nullptr;       // GAP partial sums
   bool relu = false;
-  // stem-fused first conv: raw Pel planes
-  const int16_t *org = nullptr, *pred = nullptr;
-  long org_rs = 0, org_cs = 0, pred_rs = 0, pred_cs = 0;
-  const void *stem_w = nullptr;
-  float stem_scale = 1.f;
   size_t x_lo = 0, y_lo = 0, res_lo = 0, ysc_lo = 0;  // exact mode: byte offsets hi plane -> lo plane
 };
 
 int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const ConvIO &io, int *hout_out) {
   const int hout = hin / pc.stride > 0 ? hin / pc.stride : 1;
   *hout_out = hout;
-  const bool stem = io.org != nullptr;
   ConvArgs a{};
   a.x = io.x; a.y = io.y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = io.res; a.n = n; a.relu = io.relu ? 1 : 0;
-  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale; a.stem_scale = io.stem_scale;
-  a.org = io.org; a.pred = io.pred; a.org_row_stride = io.org_rs; a.org_cu_stride = io.org_cs;
-  a.pred_row_stride = io.pred_rs; a.pred_cu_stride = io.pred_cs; a.stem_w = io.stem_w;
+  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   const int MT = pc.mt;
@@ -222,17 +215,17 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
   auto magic = [](int d) { return (uint32_t)((0x100000000ull + d - 1) / d); };  // d >= 2 (ph, pw >= 3)
-  a.pw_magic = magic(pw); a.ph_magic = magic(ph); a.rw_magic = magic(pw + 2); a.rh_magic = magic(ph + 2);
+  a.pw_magic = magic(pw); a.ph_magic = magic(ph);
   a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
-  const int extra_lds = stem ? (spw * (ph + 2) * (pw + 2) * 4 + 15) / 16 * 16 : 0;
+  const int extra_lds = 0;
   const int hw = hout * hout;
   a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   const int grid_x = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
   char name[48];
-  std::snprintf(name, sizeof name, "%sconv3x3_s%d_%dto%d_h%d%s", stem ? "stem+" : "", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");
+  std::snprintf(name, sizeof name, "conv3x3_s%d_%dto%d_h%d%s", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");
   const double px = (double)n * hw;
-  const double flops = 2.0 * px * pc.cout * pc.cin * (pc.taps + (pc.has_sc ? 1 : 0)) + (stem ? 2.0 * n * hin * hin * 32 * 18 : 0.0);
-  const double in_bytes = stem ? (double)n * hin * hin * 4 : (double)n * hin * hin * pc.cin * 2;
+  const double flops = 2.0 * px * pc.cout * pc.cin * (pc.taps + (pc.has_sc ? 1 : 0));
+  const double in_bytes = (double)n * hin * hin * pc.cin * 2;
   const double bytes = in_bytes + px * pc.cout * 2 * ((io.y ? 1 : 0) + (io.y_sc ? 1 : 0) + (io.res ? 1 : 0)) + (double)pc.w.size() * 2;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -243,6 +236,38 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
   return MLT_OK;
+}
+
+// First layer: raw Pel planes -> t = relu(bn1(conv1(stem x))) and sc = bn(shortcut(stem x)) in one composed kernel.
+int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
+              long pred_rs, long pred_cs, void *y, void *y_sc, size_t lo_off) {
+  const int hout = S / 2;
+  Stem5Args a{};
+  a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
+  a.w = pc.d_w; a.bias = pc.d_bias; a.bias_sc = pc.d_bias_sc; a.y = y; a.y_sc = y_sc;
+  a.y_lo_off = lo_off; a.ysc_lo_off = lo_off; a.w_lo_off = pc.plane_halves * 2; a.acc_scale = pc.acc_scale;
+  a.n = n; a.s_l = ilog2(S); a.hout_l = ilog2(hout);
+  const int MT = 256;
+  const int tw = hout < 32 ? hout : 32;
+  const int th = MT / tw < hout ? MT / tw : hout;
+  const int spw = MT / (tw * th);
+  a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
+  a.rh = 2 * th + 3; a.rw = 2 * tw + 3; a.halfw = (a.rw + 1) / 2;
+  a.rw_magic = (uint32_t)((0x100000000ull + a.rw - 1) / a.rw);
+  a.rh_magic = (uint32_t)((0x100000000ull + a.rh - 1) / a.rh);
+  const int lds = spw * a.rh * 2 * a.halfw * 4;
+  const int grid_x = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
+  char name[48];
+  std::snprintf(name, sizeof name, "stem5x5_s2_2to32_h%d+sc", hout);
+  const double px = (double)n * hout * hout;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18), (double)n * S * S * 4 + px * 32 * 2 * 2, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_stem5(a, pc.exact, grid_x, lds, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  if ((rc = debug_dump(ctx, name, y, (size_t)px * 32 * 2))) return rc;
+  return debug_dump(ctx, (std::string(name) + "_sc").c_str(), y_sc, (size_t)px * 32 * 2);
 }
 
 // One chunk of n CUs through the whole network, everything on ctx->stream.
@@ -286,10 +311,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
     io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
     if (s == 0) {
-      io.org = d_org; io.pred = d_pred; io.org_rs = org_rs; io.org_cs = org_cs; io.pred_rs = pred_rs; io.pred_cs = pred_cs;
-      io.stem_w = m.stem.d_w; io.stem_scale = m.stem.acc_scale;
-    }
-    if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      hout = ho;
+      if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
+    } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
     io = ConvIO();
     io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
     io.x_lo = io.y_lo = io.res_lo = lo_st;

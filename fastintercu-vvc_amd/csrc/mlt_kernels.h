@@ -20,23 +20,30 @@ struct ConvArgs {
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
   float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
-  float stem_scale;            // STEM: stem accumulators * this = stem activation (2^-s / 1023)
   // SC variant: second output = bn(conv1x1_stride2(x)) (projection shortcut, arch:44-50)
   void *y_sc;
   const float *bias_sc;
   // fp32 global-average-pool partial sums [n][gap_slots][COUT] (NULL: none); gap_l = log2(lanes per sample)
   float *gap;
   int gap_slots, gap_l;
-  // STEM variant: raw Pel planes instead of x
-  const int16_t *org, *pred;
-  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
-  const void *stem_w;          // packed stem weights (2 KiB)
-  uint32_t rw_magic, rh_magic; // raw patch dims are (ph + 2) x (pw + 2)
   // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };
 
 struct ConvCfg { int kc, ct, mt, gt; };  // cin chunk, couts / pixels per workgroup, taps per weight step
+
+struct Stem5Args {
+  const int16_t *org, *pred;   // Pel planes
+  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
+  const void *w;               // [plane][7 k-steps][64 lanes][8 halves]: 5 composed 5x5(+border) steps, 2 shortcut steps
+  const float *bias, *bias_sc;
+  void *y, *y_sc;              // t and sc, [n][S/2][S/2][32] fp16
+  size_t y_lo_off, ysc_lo_off, w_lo_off;
+  float acc_scale;
+  int n, s_l, hout_l, tw_l, th_l, spw_l;
+  int rh, rw, halfw;           // raw patch rows, cols, half row pitch (columns are parity-split)
+  uint32_t rw_magic, rh_magic;
+};
 
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
@@ -52,4 +59,5 @@ struct HeadArgs {
 
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
+hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -50,29 +50,6 @@ __device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
   return *(uint32_t *)&hv;
 }
 
-// Stem MFMA for one 32-pixel block: B fragments gathered from the raw (org,resi) LDS patch.
-// k = 2*tap + channel; k-step 0: lane half h supplies taps 4h..4h+3; k-step 1: tap 8 (h = 0), rest zero.
-__device__ __forceinline__ float16v stem_mma(const uint32_t *raw, int ridx, int rw, int h, half8 a0, half8 a1) {
-  uint32_t d[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int t = 4 * h + e;
-    const int dy = t / 3, dx = t - dy * 3;
-    d[e] = raw[ridx + dy * rw + dx];
-  }
-  const uint32_t d8 = h == 0 ? raw[ridx + 2 * rw + 2] : 0u;
-  half8 b0, b1;
-  uint32_t *b0w = (uint32_t *)&b0, *b1w = (uint32_t *)&b1;
-  b0w[0] = d[0]; b0w[1] = d[1]; b0w[2] = d[2]; b0w[3] = d[3];
-  b1w[0] = d8; b1w[1] = 0; b1w[2] = 0; b1w[3] = 0;
-  float16v acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-  return acc;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Generic conv (3x3 pad 1 or 1x1 pad 0, stride 1 or 2), NHWC fp16 -> NHWC fp16, fp32 accumulate.
 // One workgroup: MT = 32*WPB*WAVES_P output pixels (SPW samples x TH x TW) x CT = 32*WCB*WAVES_C
@@ -80,15 +57,13 @@ __device__ __forceinline__ float16v stem_mma(const uint32_t *raw, int ridx, int 
 // and reused by all taps; weights stream through a double-buffered LDS ring by LDS-DMA, GT taps per step.
 //   SC   : the block's 1x1 stride-2 projection shortcut (arch:44-50) rides along as weight "tap 9" on the
 //          same patch and leaves through a second accumulator / output (y_sc).
-//   STEM : the patch is not loaded but COMPUTED: raw Pel planes -> stem conv (arch:277-278) -> LDS, so the
-//          stem activation (1 MiB per 128x128 CU) never touches HBM.
 //   gap  : fp32 per-channel partial sums of the activated output (global average pooling, arch:282).
 // ---------------------------------------------------------------------------------------------
 //   NSPLIT = 2 ("exact" mode): every activation and weight is an fp16 (hi, lo) pair with hi + lo == the fp32
 //          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
 //          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
 //          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
   constexpr int NCHUNK = CIN / KC;
@@ -111,7 +86,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   static_assert(TT % GT == 0, "tap grouping");
   static_assert(COUT % CT == 0, "cout tiling");
   static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
-  static_assert(!STEM || (CIN == 32 && NCHUNK == 1), "stem feeds the first 32-channel conv");
   static_assert(RB >= 1 && RB <= 4, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,85 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
 
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
     if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk's patch / weights
-    if constexpr (STEM) {
-      // ---- raw (org,resi) patch -> LDS, then the stem conv writes the 32-channel patch ----
-      uint32_t *raw = (uint32_t *)(wring + NBUF * NSPLIT * WCHUNK);
-      const int RH = PH + 2, RW = PW + 2;
-      const int raw_items = (1 << spw_l) * RH * RW;
-      constexpr int UR = 4;
-      {
-        // item = raw pixel; (rr, rx) advance by NT pixels per step with one carry (no per-item division)
-        const int step_r = udiv_magic(NT, a.rw_magic), step_x = NT - step_r * RW;
-        int rr = udiv_magic(tid, a.rw_magic), rx = tid - rr * RW;
-        for (int it0 = tid; it0 < raw_items; it0 += UR * NT) {
-          int16_t vo[UR], vp[UR];
-          bool in[UR];
-#pragma unroll
-          for (int u = 0; u < UR; ++u) {
-            const int it = it0 + u * NT;
-            const int s = udiv_magic(rr, a.rh_magic), ry = rr - s * RH;
-            const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-            in[u] = it < raw_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-            // masked lanes read a valid, per-lane / per-workgroup distinct element (never one shared hot line)
-            const size_t oo = in[u] ? (size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n0 * a.org_cu_stride + (tid & (Hin - 1));
-            const size_t po = in[u] ? (size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n0 * a.pred_cu_stride + (tid & (Hin - 1));
-            vo[u] = a.org[oo];   // branch-free (clamped address), see the patch staging below
-            vp[u] = a.pred[po];
-            rx += step_x; rr += step_r;
-            if (rx >= RW) { rx -= RW; ++rr; }
-          }
-#pragma unroll
-          for (int u = 0; u < UR; ++u) {
-            const int it = it0 + u * NT;
-            if (it < raw_items) raw[it] = in[u] ? prep_pair(vo[u], vp[u]) : 0u;
-          }
-        }
-      }
-      const half8 a0 = *(const half8 *)((const char *)a.stem_w + lane * 16);
-      const half8 a1 = *(const half8 *)((const char *)a.stem_w + 1024 + lane * 16);
-      half8 a0l, a1l;
-      if constexpr (NSPLIT == 2) {  // lo plane of the stem weights: inputs are exact integers, so 2 passes suffice
-        a0l = *(const half8 *)((const char *)a.stem_w + 2048 + lane * 16);
-        a1l = *(const half8 *)((const char *)a.stem_w + 3072 + lane * 16);
-      }
-      __syncthreads();
-      const int stem_px = (1 << spw_l) * PH * PW;
-      const int sstep_r = udiv_magic(32 * NW, a.pw_magic), sstep_x = 32 * NW - sstep_r * PW;
-      int sr = udiv_magic(wave * 32 + p, a.pw_magic), sx = wave * 32 + p - sr * PW;
-      for (int pb = wave; pb * 32 < stem_px; pb += NW) {
-        const bool ok = pb * 32 + p < stem_px;
-        const int rcl = ok ? sr : 0, px = ok ? sx : 0;
-        const int s = udiv_magic(rcl, a.ph_magic), py = rcl - s * PH;
-        sx += sstep_x; sr += sstep_r;
-        if (sx >= PW) { sx -= PW; ++sr; }
-        float16v v = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0, a1);
-        if constexpr (NSPLIT == 2) {
-          const float16v vl = stem_mma(raw, (s * RH + py) * RW + px, RW, h, a0l, a1l);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += vl[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] *= a.stem_scale;  // 2^-s / 1023 (EncCu.cpp:836,838), exact in fp32 up to one rounding
-        int iy = iy0 + py, ix = ix0 + px;
-        // outside the picture the conv sees ZERO padding of the stem activation, not stem(padded input)
-        const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-        if (ok) {
-          int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-          char *dst = patch + ((s * PH + py) * RP + col) * PS + 8 * h;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            half4 o, ol;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = inside ? (_Float16)v[4 * q + e] : (_Float16)0.f;
-              ol[e] = (_Float16)(inside ? v[4 * q + e] - (float)o[e] : 0.f);
-            }
-            *(half4 *)(dst + 16 * q) = o;
-            if constexpr (NSPLIT == 2) *(half4 *)(dst + a.patch_bytes + 16 * q) = ol;
-          }
-        }
-      }
-    } else {
+    {
       // ---- stage the input patch chunk: global (16 B / lane) -> LDS, UN independent loads in flight per lane ----
       const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
       constexpr int UN = (STRIDE == 2 ? 10 : 6) / NSPLIT;  // loads in flight per lane: one round trip for the usual patch
@@ -576,6 +472,159 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// First layer, composed.  The stem conv has neither BN nor ReLU (arch:277-278: out = conv1(x), then layer0), so
+//   t  = relu(bn1(conv3x3_s2(stem(x))))   is ONE linear 5x5 stride-2 conv of the 2 raw channels (+ bias, ReLU), and
+//   sc = bn(conv1x1_s2(stem(x)))          is ONE linear 3x3 stride-2 conv of the raw channels.
+// The only place the two-step form differs is conv1's ZERO padding of the stem activation (row -1 / column -1 of the
+// stem map): the composed conv would see stem(padded input) there.  That affects output row 0 and column 0 only and
+// is cancelled exactly by extra K entries whose B operand is the raw input row 0 / column 0 (/ pixel (0,0)), masked to
+// those output pixels (weights: mlt_model.cpp pack_stem5; algebra checked to 1e-15 against the two-step form).
+// GEMM per 32-pixel block: K = 40 dword slots (25 taps + 5 top + 5 left + 1 corner + 4 pad) x 2 channels = 5 k-steps for
+// t, 2 k-steps for sc, B fragments gathered with ds_read_b32 straight from the raw (org, |org-pred|) LDS patch.
+// HBM traffic per CU: 64 KiB of Pel planes in, 2 x 256 KiB (S = 128) out; the stem activation never exists.
+// ---------------------------------------------------------------------------------------------
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *raw = (uint32_t *)smem;
+  constexpr int NT = 256, WPB = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l, hout_l = a.hout_l;
+  const int TW = 1 << tw_l, TH = 1 << th_l, S = 1 << a.s_l;
+  const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;
+  int mtile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    mtile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tx = mtile & ((1 << txs_l) - 1);
+  const int ty = (mtile >> txs_l) & ((1 << tys_l) - 1);
+  const int n0 = (mtile >> (txs_l + tys_l)) << spw_l;
+  const int RH = a.rh, RW = a.rw, HW = a.halfw, RP = 2 * HW;  // raw patch rows / cols, parity-split row pitch
+  const int iy0 = 2 * (ty << th_l) - 2, ix0 = 2 * (tx << tw_l) - 2;
+
+  // ---- raw (org,resi) patch -> LDS; even columns first, odd columns at +HW (stride-2 taps become unit stride) ----
+  {
+    const int raw_items = (1 << spw_l) * RH * RW;
+    const int step_r = udiv_magic(NT, a.rw_magic), step_x = NT - step_r * RW;
+    int rr = udiv_magic(tid, a.rw_magic), rx = tid - rr * RW;
+    constexpr int UR = 6;
+    for (int it0 = tid; it0 < raw_items; it0 += UR * NT) {
+      int16_t vo[UR], vp[UR];
+      bool in[UR];
+      int dst[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int it = it0 + u * NT;
+        const int s = udiv_magic(rr, a.rh_magic), ry = rr - s * RH;
+        const int iy = iy0 + ry, ix = ix0 + rx;
+        in[u] = it < raw_items && iy >= 0 && iy < S && ix >= 0 && ix < S && (n0 + s) < a.n;
+        dst[u] = it < raw_items ? rr * RP + (rx & 1) * HW + (rx >> 1) : -1;
+        const size_t oo = in[u] ? (size_t)(n0 + s) * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n0 * a.org_cu_stride + (tid & (S - 1));
+        const size_t po = in[u] ? (size_t)(n0 + s) * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n0 * a.pred_cu_stride + (tid & (S - 1));
+        vo[u] = a.org[oo];
+        vp[u] = a.pred[po];
+        rx += step_x; rr += step_r;
+        if (rx >= RW) { rx -= RW; ++rr; }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        if (dst[u] >= 0) raw[dst[u]] = in[u] ? prep_pair(vo[u], vp[u]) : 0u;
+    }
+  }
+  // ---- A fragments (weights) stay in registers: 5 k-steps for t, 2 for sc, per split plane ----
+  half8 am[NSPLIT][5], as[NSPLIT][2];
+#pragma unroll
+  for (int sp = 0; sp < NSPLIT; ++sp) {
+    const char *w = (const char *)a.w + sp * a.w_lo_off;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) am[sp][k] = *(const half8 *)(w + k * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) as[sp][k] = *(const half8 *)(w + (5 + k) * 1024 + lane * 16);
+  }
+  __syncthreads();
+
+  // raw offset of tap (u, v) relative to the pixel origin (row 2y, column 2x): columns are parity-split
+  auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
+  auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
+  const int m_valid = 1 << (tw_l + th_l + spw_l);
+#pragma unroll
+  for (int j = 0; j < WPB; ++j) {
+    const int m = (wave * WPB + j) * 32 + p;
+    bool ok = m < m_valid;
+    const int mm = ok ? m : 0;
+    const int x = mm & (TW - 1), y = (mm >> tw_l) & (TH - 1), s = mm >> (tw_l + th_l);
+    const int gy = (ty << th_l) + y, gx = (tx << tw_l) + x;
+    ok = ok && (n0 + s) < a.n;
+    const int o = (s * RH + 2 * y) * RP + x;          // pixel origin = input (2y-2, 2x-2)
+    const bool top = gy == 0, left = gx == 0;
+    const int orow0 = (s * RH + 2) * RP;              // raw row of input row 0 (tiles with ty == 0)
+    // value of K slot `slot` for this pixel (slot is a compile-time constant at every call site)
+    auto slot_val = [&](int slot) -> uint32_t {
+      if (slot < 25) return raw[o + main_off(slot)];
+      if (slot < 30) { const uint32_t v = raw[top ? orow0 + x + tap(0, slot - 25) : o]; return top ? v : 0u; }                 // in(0, 2x-2+v)
+      if (slot < 35) { const uint32_t v = raw[left ? o + (slot - 30) * RP + 1 : o]; return left ? v : 0u; }                    // in(2y-2+u, 0)
+      if (slot == 35) { const uint32_t v = raw[(top && left) ? orow0 + 1 : o]; return (top && left) ? v : 0u; }                // in(0, 0)
+      return 0u;
+    };
+    float16v acc, accs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accs[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      half8 b;
+      uint32_t *bw = (uint32_t *)&b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ks < 3) bw[e] = raw[o + (h ? main_off(8 * ks + 4 + e) : main_off(8 * ks + e))];  // both halves are plain taps
+        else { const uint32_t v0 = slot_val(8 * ks + e), v1 = slot_val(8 * ks + 4 + e); bw[e] = h ? v1 : v0; }
+      }
+#pragma unroll
+      for (int sp = 0; sp < NSPLIT; ++sp) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[sp][ks], b, acc, 0, 0, 0);
+    }
+    // shortcut: 3x3 stride-2 taps (b_y, b_x) at raw offset tap(1 + b_y, 1 + b_x); slots 0..8 of 16
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 b;
+      uint32_t *bw = (uint32_t *)&b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t0 = 8 * ks + e, t1 = 8 * ks + 4 + e;  // slot for h = 0 / h = 1
+        const uint32_t v0 = t0 < 9 ? raw[o + tap(1 + t0 / 3, 1 + t0 % 3)] : 0u;
+        const uint32_t v1 = t1 < 9 ? raw[o + tap(1 + t1 / 3, 1 + t1 % 3)] : 0u;
+        bw[e] = h ? v1 : v0;
+      }
+#pragma unroll
+      for (int sp = 0; sp < NSPLIT; ++sp) accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[sp][ks], b, accs, 0, 0, 0);
+    }
+    if (ok) {
+      const size_t ob = ((((size_t)(n0 + s) << hout_l) + gy) << hout_l) * 32 + (size_t)gx * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4v b1 = *(const float4v *)(a.bias + 4 * h + 8 * q), bs = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
+        half4 t, tl, c, cl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float vt = fmaxf(acc[4 * q + e] * a.acc_scale + b1[e], 0.f);  // relu(bn1(conv1(stem)))
+          const float vc = accs[4 * q + e] * a.acc_scale + bs[e];             // bn(shortcut conv(stem))
+          t[e] = (_Float16)vt; tl[e] = (_Float16)(vt - (float)t[e]);
+          c[e] = (_Float16)vc; cl[e] = (_Float16)(vc - (float)c[e]);
+        }
+        *(half4 *)((_Float16 *)a.y + ob + 8 * q) = t;
+        *(half4 *)((_Float16 *)a.y_sc + ob + 8 * q) = c;
+        if constexpr (NSPLIT == 2) {
+          *(half4 *)((char *)((_Float16 *)a.y + ob + 8 * q) + a.y_lo_off) = tl;
+          *(half4 *)((char *)((_Float16 *)a.y_sc + ob + 8 * q) + a.ysc_lo_off) = cl;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Heads + argmax (arch:282-297, EncCu.cpp:913-921).  One workgroup per CU; fp32 throughout.
 // feat = (sum of the GAP partial sums written by the stage's last conv) / HW
@@ -623,9 +672,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, bool STEM, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, STEM, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
@@ -645,12 +694,6 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 // Per layer shape: cin chunk (KC), wave tiling and taps per weight step.  mlt_conv_cfg() is the single
 // table both the launcher and the host (packing, patch sizing) read.
 // build-time tuning knobs (scripts/sweep_cfg.py): taps per weight step / ring depth of selected kernels
-#ifndef CFG_STEM_GT
-#define CFG_STEM_GT 10
-#endif
-#ifndef CFG_STEM_RB
-#define CFG_STEM_RB 1
-#endif
 #ifndef CFG_3264_GT
 #define CFG_3264_GT 10
 #endif
@@ -663,7 +706,6 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
-    {32, 32, 2, {32, 32}, 1, 1, 1, 4, {CFG_STEM_GT, 2}},     // stem-fused, + shortcut (TT = 10)
     {32, 32, 1, {32, 32}, 1, 2, 1, 8, {9, 3}},
     {32, 64, 2, {32, 32}, 2, 1, 1, 4, {CFG_3264_GT, 1}},
     {64, 64, 1, {64, 32}, 2, 2, 1, 4, {1, 1}},
@@ -690,26 +732,31 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 }
 
 // RBF / RBE: weight-ring depth (fast / exact).  Must mirror kCfg.
-#define CONV_CASE(CIN, COUT, STRIDE, SCF, STEMF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE)                                    \
+#define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE)                                    \
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
-    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF>(a, grid_x, extra_lds, st); \
-    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, STEMF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE>(a, grid_x, extra_lds, st);           \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE>(a, grid_x, extra_lds, st);           \
   }
 
-// stride-2 convs always carry their block's projection shortcut; the 32->32 one is also fed by the fused stem.
+// stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  CONV_CASE(32, 32, 2, true, true, 32, 32, 1, 1, 1, 4, CFG_STEM_GT, 2, CFG_STEM_RB, 2)
-  CONV_CASE(32, 32, 1, false, false, 32, 32, 1, 2, 1, 8, 9, 3, 1, 2)
-  CONV_CASE(32, 64, 2, true, false, 32, 32, 2, 1, 1, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
-  CONV_CASE(64, 64, 1, false, false, 64, 32, 2, 2, 1, 4, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(64, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
-  CONV_CASE(128, 128, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(128, 256, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
-  CONV_CASE(256, 256, 1, false, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(64, 96, 2, true, false, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
-  CONV_CASE(96, 96, 1, false, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
-  CONV_CASE(96, 128, 2, true, false, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(32, 32, 1, false, 32, 32, 1, 2, 1, 8, 9, 3, 1, 2)
+  CONV_CASE(32, 64, 2, true, 32, 32, 2, 1, 1, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
+  CONV_CASE(64, 64, 1, false, 64, 32, 2, 2, 1, 4, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(64, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(128, 128, 1, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(128, 256, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(256, 256, 1, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
+  CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
+  CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
   return hipErrorInvalidValue;
+}
+
+hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st) {
+  if (exact) hipLaunchKernelGGL(stem5_kernel<2>, dim3(grid_x), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(stem5_kernel<1>, dim3(grid_x), dim3(256), lds, st, a);
+  return hipGetLastError();
 }
 
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st) {

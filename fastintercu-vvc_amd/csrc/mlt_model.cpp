@@ -144,29 +144,64 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
   }
 }
 
-// Stem: K index k = 2*tap + channel (18 used of 32), cout = 32.  The kernel feeds exact integer fp16 inputs, so the
-// 1/1023 input scale (EncCu.cpp:836,838) is applied to the fp32 accumulator (acc_scale = 2^-s / 1023), NOT folded
-// into the fp16 weights: w/1023 ~ 1e-4 would sit in fp16's subnormal range and keep only ~10 significant bits.
-static void pack_stem(PackedConv &pc, const float *w) {
-  pc.plane_halves = 2 * 64 * 8;
+// First layer, composed (kernel: stem5_kernel).  The stem conv has no BN / ReLU (arch:277-278), so with
+//   W1 = layer0.0.conv1 folded with bn1, Wsc = layer0.0.shortcut folded with its BN, Ws = stem conv1:
+//   W5[co][c][u][v]  = sum_cm sum_{a+b=(u,v)} W1[co][cm][a] * Ws[cm][c][b]      (5x5, stride 2, pad 2)
+//   Wsc3[co][c][b]   = sum_cm Wsc[co][cm] * Ws[cm][c][b]                        (3x3, stride 2, pad 1)
+// conv1 pads the STEM activation with zeros, the composed conv pads the INPUT; they differ where conv1 reads stem
+// row -1 / column -1, i.e. for output row 0 / column 0.  The difference is cancelled by extra K slots:
+//   Top[co][c][v]  = -sum_cm sum_{ax+bx=v} W1[co][cm][0][ax] * Ws[cm][c][2][bx]   x in(0, 2x-2+v)    (output row 0)
+//   Left[co][c][u] = -sum_cm sum_{ay+by=u} W1[co][cm][ay][0] * Ws[cm][c][by][2]   x in(2y-2+u, 0)    (output column 0)
+//   Corner[co][c]  = +sum_cm W1[co][cm][0][0] * Ws[cm][c][2][2]                   x in(0, 0)         (output (0,0))
+// K slot order (one slot = the (org, resi) pair of one tap): 25 taps, 5 top, 5 left, 1 corner, 4 zero = 40 slots =
+// 5 MFMA k-steps; then the 9 shortcut taps in 2 k-steps.  Inputs are exact integers in fp16, so the 1/1023 scale
+// (EncCu.cpp:836,838) rides in the weights together with 2^12 (acc_scale = 2^-12) to keep them in fp16's normal range.
+static void pack_stem5(PackedConv &pc, const float *ws, const float *w1, const std::vector<double> &s1, const float *wsc,
+                       const std::vector<double> &ssc) {
+  auto Ws = [&](int cm, int c, int by, int bx) { return (double)ws[((cm * 2 + c) * 3 + by) * 3 + bx]; };
+  auto W1 = [&](int co, int cm, int ay, int ax) { return (double)w1[((co * 32 + cm) * 3 + ay) * 3 + ax] * s1[co]; };
+  auto Wsc = [&](int co, int cm) { return (double)wsc[co * 32 + cm] * ssc[co]; };
+  const double mul = (double)(float)(1.0 / 1023) * 4096.0;
+  pc.acc_scale = 1.0f / 4096.0f;
+  pc.plane_halves = 7 * 64 * 8;
   pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
+  auto store = [&](int kstep0, int slot, int co, int c, double exact, double *err) {
+    const int k = 2 * slot + c, ks = kstep0 + k / 16, hh = (k % 16) / 8, j = k % 8;
+    const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
+    if (pc.exact) {
+      const uint16_t q = f32_to_f16((float)exact);
+      pc.w[idx] = q;
+      pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
+    } else {
+      const double tgt = err ? exact - *err : exact;
+      const uint16_t q = f32_to_f16((float)tgt);
+      if (err) *err += (double)f16_to_f32(q) - exact;
+      pc.w[idx] = q;
+    }
+  };
   for (int co = 0; co < 32; ++co)
     for (int c = 0; c < 2; ++c) {
-      double err = 0.0;
-      for (int t = 0; t < 9; ++t) {
-        const double exact = (double)w[((size_t)co * 2 + c) * 9 + t] * 16.0;  // 2^4: |w| ~ 0.1 -> ~1.6
-        const int k = 2 * t + c, ks = k / 16, hh = (k % 16) / 8, j = k % 8;
-        const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
-        if (pc.exact) {
-          const uint16_t q = f32_to_f16((float)exact);
-          pc.w[idx] = q;
-          pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
-        } else {
-          const uint16_t q = f32_to_f16((float)(exact - err));
-          err += (double)f16_to_f32(q) - exact;
-          pc.w[idx] = q;
-        }
+      double w5[5][5] = {}, top[5] = {}, left[5] = {}, corner = 0.0, sc3[3][3] = {};
+      for (int cm = 0; cm < 32; ++cm) {
+        for (int ay = 0; ay < 3; ++ay)
+          for (int ax = 0; ax < 3; ++ax)
+            for (int by = 0; by < 3; ++by)
+              for (int bx = 0; bx < 3; ++bx) w5[ay + by][ax + bx] += W1(co, cm, ay, ax) * Ws(cm, c, by, bx);
+        for (int ax = 0; ax < 3; ++ax)
+          for (int bx = 0; bx < 3; ++bx) top[ax + bx] -= W1(co, cm, 0, ax) * Ws(cm, c, 2, bx);
+        for (int ay = 0; ay < 3; ++ay)
+          for (int by = 0; by < 3; ++by) left[ay + by] -= W1(co, cm, ay, 0) * Ws(cm, c, by, 2);
+        corner += W1(co, cm, 0, 0) * Ws(cm, c, 2, 2);
+        for (int by = 0; by < 3; ++by)
+          for (int bx = 0; bx < 3; ++bx) sc3[by][bx] += Wsc(co, cm) * Ws(cm, c, by, bx);
       }
+      double err = 0.0;  // tap-diffused rounding over the 25 taps (fast mode), plain rounding for the rest
+      for (int t = 0; t < 25; ++t) store(0, t, co, c, w5[t / 5][t % 5] * mul, &err);
+      for (int v = 0; v < 5; ++v) store(0, 25 + v, co, c, top[v] * mul, nullptr);
+      for (int u = 0; u < 5; ++u) store(0, 30 + u, co, c, left[u] * mul, nullptr);
+      store(0, 35, co, c, corner * mul, nullptr);
+      double err_sc = 0.0;
+      for (int t = 0; t < 9; ++t) store(5, t, co, c, sc3[t / 3][t % 3] * mul, &err_sc);
     }
 }
 
@@ -193,14 +228,18 @@ bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::stri
   m.n_heads = m.n_stages - 1;
 
   err.clear();
-  {
-    const float *w = b.find("conv1.weight", 32 * 2 * 9, err);
-    if (!w) return false;
-    m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 9; m.stem.stride = 1; m.stem.kc = 32; m.stem.ct = 32;
+  {  // first layer: stem composed with layer0.0.conv1 (+bn1) and layer0.0.shortcut (+BN)
+    const float *ws = b.find("conv1.weight", 32 * 2 * 9, err);
+    const float *w1 = b.find("layer0.0.conv1.weight", 32 * 32 * 9, err);
+    const float *wsc = b.find("layer0.0.shortcut.0.weight", 32 * 32, err);
+    if (!ws || !w1 || !wsc) return false;
+    std::vector<double> s1, ssc;
+    m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 25; m.stem.stride = 2; m.stem.kc = 32; m.stem.ct = 32; m.stem.has_sc = true;
     m.stem.exact = exact;
-    m.stem.acc_scale = (float)((double)(float)(1.0 / 1023) / 16.0);
-    pack_stem(m.stem, w);
-    m.stem.bias.assign(32, 0.f);
+    fold_scale(b, "layer0.0.bn1", 32, s1, m.stem.bias, err);
+    fold_scale(b, "layer0.0.shortcut.1", 32, ssc, m.stem.bias_sc, err);
+    if (!err.empty()) return false;
+    pack_stem5(m.stem, ws, w1, s1, wsc, ssc);
   }
   int cin = 32;
   char nm[96];
@@ -235,7 +274,8 @@ bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::stri
         return true;
       };
       const bool has_sc = (st != 1 || bin != c);  // arch:44-45
-      if (!make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
+      if (!(s == 0 && bi == 0) &&  // layer0.0.conv1 + shortcut live in the composed first layer (m.stem)
+          !make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
       if (!make(B.conv2, "conv2.weight", "bn2", c, 1, false)) return false;
     }
     cin = c;
