@@ -50,6 +50,29 @@ __device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
   return *(uint32_t *)&hv;
 }
 
+
+// ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------
+// After a 32x32 MFMA lane l = (p, h) holds, per register quad q, output channels 8q+4h .. 8q+4h+3 of pixel p, so
+// lanes p and p+32 own the two 8-byte halves of one 16-byte span.  v_permlane32_swap exchanges the upper half-wave
+// of its first operand with the lower half-wave of its second: applied to quads (q, q+1) it leaves lanes 0-31 with
+// channels 8q..8q+7 and lanes 32-63 with channels 8(q+1)..8(q+1)+7 -> ONE dwordx4 access per quad pair instead of
+// two dwordx2 (half the memory instructions / requests, same bytes; cdna_hip_programming.md T21).
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4v pair16(half4 qa, half4 qb) {
+  uint32_t ax = ((uint32_t *)&qa)[0], ay = ((uint32_t *)&qa)[1], bx = ((uint32_t *)&qb)[0], by = ((uint32_t *)&qb)[1];
+  auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+  uint4v v;
+  v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
+  return v;
+}
+__device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // inverse of pair16 (the swap is an involution)
+  auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+  ((uint32_t *)&qa)[0] = r0[0]; ((uint32_t *)&qa)[1] = r1[0];
+  ((uint32_t *)&qb)[0] = r0[1]; ((uint32_t *)&qb)[1] = r1[1];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic conv (3x3 pad 1 or 1x1 pad 0, stride 1 or 2), NHWC fp16 -> NHWC fp16, fp32 accumulate.
 // One workgroup: MT = 32*WPB*WAVES_P output pixels (SPW samples x TH x TW) x CT = 32*WCB*WAVES_C
@@ -333,18 +356,20 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
 
   // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
-  // residual reads first, all of them, so they are in flight together (and never queue behind the stores)
-  half4 resv[WCB][WPB][4], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][4];
+  // residual reads first, all of them, so they are in flight together (and never queue behind the stores);
+  // 16 bytes per lane: lanes 0-31 fetch channels 8q..8q+7, lanes 32-63 channels 8(q+1).. of quad pairs (q, q+1)
+  uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
   if (a.res) {
 #pragma unroll
     for (int i = 0; i < WCB; ++i)
 #pragma unroll
       for (int j = 0; j < WPB; ++j) {
-        const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 4 * h;
+        // clamped address (channel offset only when the pixel is invalid): branch-free
+        const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // clamped address (o = channel offset only when the pixel is invalid): branch-free
-          resv[i][j][q] = *(const half4 *)((const _Float16 *)a.res + o + 8 * q);
-          if constexpr (NSPLIT == 2) resl[i][j][q] = *(const half4 *)((const char *)((const _Float16 *)a.res + o + 8 * q) + a.res_lo_off);
+        for (int qq = 0; qq < 2; ++qq) {
+          resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+          if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
         }
       }
   }
@@ -360,44 +385,52 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
       const bool ok = opix[j] >= 0;
-      const size_t o = (size_t)(ok ? opix[j] : 0) * COUT + cbase;
+      const size_t o16 = (size_t)(ok ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;  // this lane's 16-byte span of quad pair 0
       float v[16];
+      half4 hq[4], hl[4], sq[4], sl[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int qq = 0; qq < 2; ++qq) {
+        half4 ra, rb, rla, rlb;
+        if (a.res) {  // uniform
+          unpair16(resv[i][j][qq], ra, rb);
+          if constexpr (NSPLIT == 2) unpair16(resl[i][j][qq], rla, rlb);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] * a.acc_scale + bq[q][e];
-        if (a.res) {
+        for (int k = 0; k < 2; ++k) {
+          const int q = 2 * qq + k;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[4 * q + e] += (float)resv[i][j][q][e];
-            if constexpr (NSPLIT == 2) v[4 * q + e] += (float)resl[i][j][q][e];
+            float x = acc[i][j][4 * q + e] * a.acc_scale + bq[q][e];
+            if (a.res) {
+              x += (float)(k ? rb[e] : ra[e]);
+              if constexpr (NSPLIT == 2) x += (float)(k ? rlb[e] : rla[e]);
+            }
+            if (a.relu) x = fmaxf(x, 0.f);
+            v[4 * q + e] = x;
+            hq[q][e] = (_Float16)x;
+            hl[q][e] = (_Float16)(x - (float)hq[q][e]);
+            if constexpr (SC) {
+              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[q][e];
+              sq[q][e] = (_Float16)vs;
+              sl[q][e] = (_Float16)(vs - (float)sq[q][e]);
+            }
           }
         }
-        if (a.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(v[4 * q + e], 0.f);
-        }
-        if (a.y && ok) {
-          half4 out, outl;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            out[e] = (_Float16)v[4 * q + e];
-            outl[e] = (_Float16)(v[4 * q + e] - (float)out[e]);
+        // every lane takes part in the swaps; only valid pixels store
+        if (a.y) {
+          const uint4v w = pair16(hq[2 * qq], hq[2 * qq + 1]);
+          if (ok) *(uint4v *)((_Float16 *)a.y + o16 + 16 * qq) = w;
+          if constexpr (NSPLIT == 2) {
+            const uint4v wl = pair16(hl[2 * qq], hl[2 * qq + 1]);
+            if (ok) *(uint4v *)((char *)((_Float16 *)a.y + o16 + 16 * qq) + a.y_lo_off) = wl;
           }
-          *(half4 *)((_Float16 *)a.y + o + 8 * q) = out;
-          if constexpr (NSPLIT == 2) *(half4 *)((char *)((_Float16 *)a.y + o + 8 * q) + a.y_lo_off) = outl;
         }
         if constexpr (SC) {
-          if (ok) {
-            half4 out, outl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[q][e];
-              out[e] = (_Float16)vs;
-              outl[e] = (_Float16)(vs - (float)out[e]);
-            }
-            *(half4 *)((_Float16 *)a.y_sc + o + 8 * q) = out;
-            if constexpr (NSPLIT == 2) *(half4 *)((char *)((_Float16 *)a.y_sc + o + 8 * q) + a.ysc_lo_off) = outl;
+          const uint4v w = pair16(sq[2 * qq], sq[2 * qq + 1]);
+          if (ok) *(uint4v *)((_Float16 *)a.y_sc + o16 + 16 * qq) = w;
+          if constexpr (NSPLIT == 2) {
+            const uint4v wl = pair16(sl[2 * qq], sl[2 * qq + 1]);
+            if (ok) *(uint4v *)((char *)((_Float16 *)a.y_sc + o16 + 16 * qq) + a.ysc_lo_off) = wl;
           }
         }
       }
@@ -601,24 +634,33 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
 #pragma unroll
       for (int sp = 0; sp < NSPLIT; ++sp) accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[sp][ks], b, accs, 0, 0, 0);
     }
-    if (ok) {
-      const size_t ob = ((((size_t)(n0 + s) << hout_l) + gy) << hout_l) * 32 + (size_t)gx * 32 + 4 * h;
+    {
+      const size_t ob = ok ? ((((size_t)(n0 + s) << hout_l) + gy) << hout_l) * 32 + (size_t)gx * 32 + 8 * h : 0;  // 16-byte span of quad pair 0
+      half4 t[4], tl[4], c[4], cl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4v b1 = *(const float4v *)(a.bias + 4 * h + 8 * q), bs = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
-        half4 t, tl, c, cl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float vt = fmaxf(acc[4 * q + e] * a.acc_scale + b1[e], 0.f);  // relu(bn1(conv1(stem)))
           const float vc = accs[4 * q + e] * a.acc_scale + bs[e];             // bn(shortcut conv(stem))
-          t[e] = (_Float16)vt; tl[e] = (_Float16)(vt - (float)t[e]);
-          c[e] = (_Float16)vc; cl[e] = (_Float16)(vc - (float)c[e]);
+          t[q][e] = (_Float16)vt; tl[q][e] = (_Float16)(vt - (float)t[q][e]);
+          c[q][e] = (_Float16)vc; cl[q][e] = (_Float16)(vc - (float)c[q][e]);
         }
-        *(half4 *)((_Float16 *)a.y + ob + 8 * q) = t;
-        *(half4 *)((_Float16 *)a.y_sc + ob + 8 * q) = c;
+      }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {  // all lanes swap, valid pixels store 16 B per lane and quad pair
+        const uint4v wt = pair16(t[2 * qq], t[2 * qq + 1]), wc = pair16(c[2 * qq], c[2 * qq + 1]);
+        if (ok) {
+          *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = wt;
+          *(uint4v *)((_Float16 *)a.y_sc + ob + 16 * qq) = wc;
+        }
         if constexpr (NSPLIT == 2) {
-          *(half4 *)((char *)((_Float16 *)a.y + ob + 8 * q) + a.y_lo_off) = tl;
-          *(half4 *)((char *)((_Float16 *)a.y_sc + ob + 8 * q) + a.ysc_lo_off) = cl;
+          const uint4v wtl = pair16(tl[2 * qq], tl[2 * qq + 1]), wcl = pair16(cl[2 * qq], cl[2 * qq + 1]);
+          if (ok) {
+            *(uint4v *)((char *)((_Float16 *)a.y + ob + 16 * qq) + a.y_lo_off) = wtl;
+            *(uint4v *)((char *)((_Float16 *)a.y_sc + ob + 16 * qq) + a.ysc_lo_off) = wcl;
+          }
         }
       }
     }
