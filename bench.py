@@ -63,13 +63,7 @@ def main():
     if rank == 0:
         blob = pkg.weights.synthetic_blob(arch, 10)
     if world > 1:
-        ln = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(ln, 0)
-        t = torch.empty(int(ln.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            t.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(t, 0)
-        blob = bytes(t.cpu().numpy().tobytes())
+        blob = pkg.shard.broadcast_blob(blob if rank == 0 else None, dist, dev)
     m = pkg.MltCnn(device=local_rank, sizes=(size,), blobs={size: blob}, max_batch=B)
 
     # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
