@@ -134,12 +134,25 @@ def main():
                         "algo_gbs": round(r["bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1)})
     if dom:
         avg_ms = dom["total_ms"] / dom["launches"]
-        ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-                    "algo_flops_per_launch": dom["flops"] / dom["launches"],
-                    "algo_bytes_per_launch": dom["bytes"] / dom["launches"]}
+        flops_l, bytes_l = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
+        # which roof binds this kernel: arithmetic intensity against the MI355X ridge (2.5 PFLOP/s / 8 TB/s ~ 310 FLOP/B)
+        mfma_bound = bytes_l > 0 and flops_l / bytes_l >= MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get(f"{dom['name']}@{B}")
+            traffic = t["hbm_bytes_per_launch"] * (B / t["batch"]) if t else None
+        if mfma_bound:
+            ach = flops_l / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+        else:
+            ach = bytes_l / (avg_ms * 1e-3) / 1e9
+            roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roofline.update({"traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                         "algo_flops_per_launch": flops_l, "algo_bytes_per_launch": bytes_l,
+                         "flop_per_byte": round(flops_l / max(bytes_l, 1.0), 1)})
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:

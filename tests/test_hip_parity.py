@@ -161,3 +161,41 @@ def test_head_index_option_and_errors(gpu):
     with pytest.raises(pkg.MltError):
         pkg.MltCnn(device=0, sizes=(128,), blobs={128: b"garbage"})
     m0.close(); m3.close()
+
+
+def test_cpp_call_site_demo_matches_python_binding(gpu, tmp_path):
+    """host/mlt_split_predictor.hpp (the C++ mirror of EncCu.cpp:746-756,806-921) driven from a plain g++ program,
+    weights read from <dir>/MLTORPQ_splitMode_128.mltw like the reference reads its .pt (EncCu.cpp:897-899)."""
+    import os
+    import subprocess
+    pkg = gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = pkg.weights.synthetic_blob(0, 10)
+    (tmp_path / "MLTORPQ_splitMode_128.mltw").write_bytes(blob)
+    exe = str(tmp_path / "callsite_demo")
+    lib_dir = os.path.dirname(pkg.build.LIB)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "host", "callsite_demo.cpp"), "-o", exe,
+                           "-L" + lib_dir, "-lmltcnn_hip", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    # same CU through the Python binding (the demo's LCG picture, re-created here)
+    picW, picH, cux, cuy, cuw = 1920, 1080, 256, 128, 128
+    lcg = 12345
+    pic = np.empty(picW * picH, np.int16)
+    vals = []
+    for _ in range(picW * picH):
+        lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+        vals.append((lcg >> 22) & 1023)
+    pic[:] = vals
+    pic = pic.reshape(picH, picW)
+    pred = np.empty((cuw, cuw), np.int16)
+    for y in range(cuw):
+        for x in range(cuw):
+            lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+            pred[y, x] = min(max(int(pic[cuy + y, cux + x]) + ((lcg >> 24) % 41) - 20, 0), 1023)
+    m = _ctx(pkg, 128, blob)
+    split, logits = m.predict(pic[cuy:cuy + cuw, cux:cux + cuw], pred, 8, 32)
+    m.close()
+    assert f"predictedSplitMode = {split} " in out.stdout, out.stdout
+    got = [float(v) for v in out.stdout.split("=")[-1].split()]
+    assert np.allclose(got, logits[5:9], atol=2e-4), (got, logits[5:9])
