@@ -51,7 +51,7 @@ struct mlt_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   SizeState sz[4];
-  int max_batch = 4096, chunk = 1024;
+  int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
   // staging for the host-pointer entry points

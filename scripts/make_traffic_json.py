@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate runs).
+HBM bytes per launch = 2 * FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)
++ WRITE_SIZE, both in KiB.  usage: make_traffic_json.py <fetch_csv> <write_csv> <batch> <out.json>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+H_BY_COUT = {32: 64, 64: 32, 128: 16, 256: 8}
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d)", k)
+        if m:
+            cin, cout, st = map(int, m.groups())
+            name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")
+        elif "stem5_kernel" in k:
+            name = "stem5x5_s2_2to32_h64+sc"
+        elif "heads_kernel" in k:
+            name = "heads"
+        else:
+            continue
+        acc[name][0] += float(r["Counter_Value"])
+        acc[name][1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+def main():
+    fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    res = {}
+    for name in f:
+        res[f"{name}@{batch}"] = {"batch": batch, "fetch_kib_raw": f[name], "write_kib": w.get(name, 0.0),
+                                  "hbm_bytes_per_launch": (2.0 * f[name] + w.get(name, 0.0)) * 1024.0,
+                                  "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts wide reads at half)"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
