@@ -745,16 +745,64 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 #ifndef CFG_S1_RB
 #define CFG_S1_RB 2
 #endif
+#ifndef CFG_64_WPB   // 64@32 stride-1: pixel blocks per wave / waves along pixels
+#define CFG_64_WPB 1
+#endif
+#ifndef CFG_64_WP
+#define CFG_64_WP 8
+#endif
+#ifndef CFG_64_WCB
+#define CFG_64_WCB 2
+#endif
+#ifndef CFG_64_WC
+#define CFG_64_WC 1
+#endif
+#ifndef CFG_S2BIG_WCB
+#define CFG_S2BIG_WCB 2
+#endif
+#ifndef CFG_S2BIG_WC
+#define CFG_S2BIG_WC 2
+#endif
+#ifndef CFG_BIG_WPB  // 128@16, 256@8 stride-1
+#define CFG_BIG_WPB 1
+#endif
+#ifndef CFG_BIG_WP
+#define CFG_BIG_WP 4
+#endif
+#ifndef CFG_BIG_WCB
+#define CFG_BIG_WCB 2
+#endif
+#ifndef CFG_S2BIG_WPB  // 64->128, 128->256 stride-2 (+shortcut)
+#define CFG_S2BIG_WPB 1
+#endif
+#ifndef CFG_S2BIG_WP
+#define CFG_S2BIG_WP 4
+#endif
+#ifndef CFG_3264_WCB   // 32->64 stride-2 (+shortcut)
+#define CFG_3264_WCB 1
+#endif
+#ifndef CFG_3264_WC
+#define CFG_3264_WC 2
+#endif
+#ifndef CFG_32_WPB     // 32@64 stride-1
+#define CFG_32_WPB 2
+#endif
+#ifndef CFG_32_WP
+#define CFG_32_WP 8
+#endif
+#ifndef CFG_BIG_WC
+#define CFG_BIG_WC 2
+#endif
 struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
-    {32, 32, 1, {32, 32}, 1, 2, 1, 8, {9, 3}},
-    {32, 64, 2, {32, 32}, 2, 1, 1, 4, {CFG_3264_GT, 1}},
-    {64, 64, 1, {64, 32}, 2, 2, 1, 4, {1, 1}},
-    {64, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
-    {128, 128, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
-    {128, 256, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
-    {256, 256, 1, {64, 32}, 2, 2, 2, 2, {1, 1}},
+    {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
+    {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
+    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {1, 1}},
+    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
+    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
+    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
     {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
@@ -782,13 +830,13 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  CONV_CASE(32, 32, 1, false, 32, 32, 1, 2, 1, 8, 9, 3, 1, 2)
-  CONV_CASE(32, 64, 2, true, 32, 32, 2, 1, 1, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
-  CONV_CASE(64, 64, 1, false, 64, 32, 2, 2, 1, 4, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(64, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
-  CONV_CASE(128, 128, 1, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(128, 256, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
-  CONV_CASE(256, 256, 1, false, 64, 32, 2, 2, 2, 2, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2)
+  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
+  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
+  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
+  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
   CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)

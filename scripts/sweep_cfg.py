@@ -11,14 +11,10 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
     "base": [],
-    "3264_gt2_rb3": ["CFG_3264_GT=2", "CFG_3264_RB=3"],
-    "3264_gt5_rb2": ["CFG_3264_GT=5", "CFG_3264_RB=2"],
-    "3264_gt10": ["CFG_3264_GT=10", "CFG_3264_RB=1"],
-    "stem_gt2_rb2": ["CFG_STEM_GT=2", "CFG_STEM_RB=2"],
-    "stem_gt5_rb2": ["CFG_STEM_GT=5", "CFG_STEM_RB=2"],
-    "stem_gt10": ["CFG_STEM_GT=10", "CFG_STEM_RB=1"],
-    "s1_rb2": ["CFG_S1_RB=2"],
-    "s1_rb4": ["CFG_S1_RB=4"],
+    "64_16w": ["CFG_64_WCB=1", "CFG_64_WC=2"],
+    "big_16w": ["CFG_BIG_WCB=1", "CFG_BIG_WC=4"],
+    "s2big_16w": ["CFG_S2BIG_WCB=1", "CFG_S2BIG_WC=4"],
+    "s1_rb3": ["CFG_S1_RB=3"],
 }
 
 
