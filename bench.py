@@ -119,6 +119,16 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- encoder-realistic call: ONE CU per synchronous mlt_predict (strided host planes in, split mode out), as
+    # EncCu.cpp:806-921 is used today; outside the timed region, informational ----
+    m.set_stream(0)
+    lat = []
+    for i in range(60):
+        c0 = time.perf_counter()
+        m.predict(org[i % B], pred[i % B], int(poc[i % B]), int(qp[i % B]))
+        lat.append(time.perf_counter() - c0)
+    batch1_us = float(np.median(lat[10:]) * 1e6)
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     # ---- roofline of the dominant kernel (largest total device time) ----
@@ -181,6 +191,7 @@ def main():
         "derived": {"model_tflops": round(value * FLOP_PER_CU / 1e12, 1),
                     "mfma_frac_whole_net": round(value / world * FLOP_PER_CU / 1e12 / MFMA_PEAK_TFLOPS, 4),
                     "hbm_layerwise_roofline_frac": round(value / world * LAYERWISE_BYTES_PER_CU / 1e9 / HBM_PEAK_GBS, 4),
+                    "batch1_sync_call_us": round(batch1_us, 1),
                     "kernels": kernels},
     }
     print(json.dumps(out))

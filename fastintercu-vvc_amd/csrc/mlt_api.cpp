@@ -42,6 +42,17 @@ struct SizeState {
   mlt::Model model;
 };
 
+// mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
+// hipGraph captured once per CU size, one D2H.
+struct SingleCu {
+  char *h_stage = nullptr, *d_stage = nullptr;  // [org plane][pred plane][poc, qp, split, pad, logits...]
+  size_t plane = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const char *ws_at_capture = nullptr;  // the graph bakes in workspace pointers
+  hipStream_t stream_at_capture = nullptr;
+};
+
 struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 
 }  // namespace
@@ -54,6 +65,7 @@ struct mlt_ctx {
   int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
+  SingleCu single[4];
   // staging for the host-pointer entry points
   char *stage = nullptr;
   size_t stage_bytes = 0;
@@ -447,6 +459,12 @@ void mlt_shutdown(mlt_ctx *ctx) {
   for (auto &kv : ctx->prof)
     for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (int i = 0; i < 4; ++i) free_model(ctx->sz[i].model);
+  for (SingleCu &sg : ctx->single) {
+    if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+    if (sg.graph) (void)hipGraphDestroy(sg.graph);
+    if (sg.h_stage) (void)hipHostFree(sg.h_stage);
+    if (sg.d_stage) (void)hipFree(sg.d_stage);
+  }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -457,8 +475,14 @@ int mlt_set_stream(mlt_ctx *ctx, void *hip_stream) {
   if (!ctx) return MLT_ERR_ARG;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  ctx->stream = (hipStream_t)hip_stream;
+  ctx->stream = nullptr;
   ctx->own_stream = false;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {  // NULL: back to a stream owned by the context
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
   return MLT_OK;
 }
 
@@ -533,21 +557,56 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   const int nl = st->model.n_logits;
   const size_t cs = (size_t)size * size;
-  const size_t plane = (cs * 2 + 255) / 256 * 256;
-  if ((rc = ensure_stage(ctx, 2 * plane + 1024))) return rc;
-  int16_t *d_org = (int16_t *)ctx->stage, *d_pred = (int16_t *)(ctx->stage + plane);
-  int32_t *d_sc = (int32_t *)(ctx->stage + 2 * plane);  // [poc, qp, split, pad, logits...]
-  // the gather of EncCu.cpp:810-830 as two strided copies (rows of `size` Pels out of a `stride`-Pel pitch)
-  HIP_TRY(ctx, hipMemcpy2DAsync(d_org, (size_t)size * 2, org, (size_t)org_stride * 2, (size_t)size * 2, size, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpy2DAsync(d_pred, (size_t)size * 2, pred, (size_t)pred_stride * 2, (size_t)size * 2, size, hipMemcpyHostToDevice, ctx->stream));
-  const int32_t sc[2] = {poc, qp};
-  HIP_TRY(ctx, hipMemcpyAsync(d_sc, sc, 8, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
-  int32_t back[4 + MLT_MAX_LOGITS];
-  HIP_TRY(ctx, hipMemcpyAsync(back, d_sc, (size_t)(4 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SingleCu &sg = ctx->single[size_index(size)];
+  if (!sg.h_stage) {
+    sg.plane = (cs * 2 + 255) / 256 * 256;
+    HIP_TRY(ctx, hipHostMalloc((void **)&sg.h_stage, 2 * sg.plane + 256, hipHostMallocDefault));
+    HIP_TRY(ctx, hipMalloc((void **)&sg.d_stage, 2 * sg.plane + 256));
+  }
+  // the gather of EncCu.cpp:810-830: rows of `size` Pels out of a `stride`-Pel pitch -> dense planes (pinned)
+  for (int y = 0; y < size; ++y) {
+    std::memcpy(sg.h_stage + (size_t)y * size * 2, org + (size_t)y * org_stride, (size_t)size * 2);
+    std::memcpy(sg.h_stage + sg.plane + (size_t)y * size * 2, pred + (size_t)y * pred_stride, (size_t)size * 2);
+  }
+  int32_t *h_sc = (int32_t *)(sg.h_stage + 2 * sg.plane);  // [poc, qp, split, pad, logits...]
+  h_sc[0] = poc; h_sc[1] = qp;
+  HIP_TRY(ctx, hipMemcpyAsync(sg.d_stage, sg.h_stage, 2 * sg.plane + 8, hipMemcpyHostToDevice, ctx->stream));
+  int16_t *d_org = (int16_t *)sg.d_stage, *d_pred = (int16_t *)(sg.d_stage + sg.plane);
+  int32_t *d_sc = (int32_t *)(sg.d_stage + 2 * sg.plane);
+  static const bool no_graph = std::getenv("MLT_NO_GRAPH") != nullptr || std::getenv("MLT_DEBUG_DUMP_DIR") != nullptr;
+  bool replayed = false;
+  if (!no_graph && !ctx->profile && ctx->own_stream) {
+    if (sg.exec && (sg.ws_at_capture != ctx->ws || sg.stream_at_capture != ctx->stream)) {  // workspace moved: re-capture
+      (void)hipGraphExecDestroy(sg.exec); (void)hipGraphDestroy(sg.graph);
+      sg.exec = nullptr; sg.graph = nullptr;
+    }
+    if (!sg.exec) {
+      // first call: run eagerly once (allocates the workspace, configures every kernel), then capture the same chain
+      if ((rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+        if (rc == MLT_OK && ce == hipSuccess && g && hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+          sg.graph = g; sg.ws_at_capture = ctx->ws; sg.stream_at_capture = ctx->stream;
+        } else {
+          if (g) (void)hipGraphDestroy(g);
+          sg.exec = nullptr;
+          (void)hipGetLastError();
+        }
+      }
+      replayed = true;  // the eager run above already produced this call's result
+    } else {
+      HIP_TRY(ctx, hipGraphLaunch(sg.exec, ctx->stream));
+      replayed = true;
+    }
+  }
+  if (!replayed && (rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  *split_mode = back[2];
-  if (logits_opt) std::memcpy(logits_opt, back + 4, (size_t)nl * 4);
+  *split_mode = h_sc[2];
+  if (logits_opt) std::memcpy(logits_opt, h_sc + 4, (size_t)nl * 4);
   return MLT_OK;
 }
 

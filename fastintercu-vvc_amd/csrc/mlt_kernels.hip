@@ -772,6 +772,9 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 #ifndef CFG_BIG_WCB
 #define CFG_BIG_WCB 2
 #endif
+#ifndef CFG_128_WPB    // 128@16 stride-1 pixel blocks per wave (256@8 uses CFG_BIG_WPB)
+#define CFG_128_WPB CFG_BIG_WPB
+#endif
 #ifndef CFG_S2BIG_WPB  // 64->128, 128->256 stride-2 (+shortcut)
 #define CFG_S2BIG_WPB 1
 #endif
@@ -800,7 +803,7 @@ static const CfgRow kCfg[] = {
     {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
     {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {1, 1}},
     {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
-    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
     {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
     {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
     // CU model (planes 32/64/96/128/256)
@@ -834,7 +837,7 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const Conv
   CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 1, 1, CFG_S1_RB, 2)
   CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
-  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
+  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
   CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
   CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)

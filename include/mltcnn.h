@@ -93,7 +93,8 @@ int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, c
 
 int mlt_synchronize(mlt_ctx *ctx);
 
-/* Use an existing hipStream_t (e.g. the caller's) instead of the context's own stream. */
+/* Use an existing hipStream_t (e.g. the caller's) instead of the context's own stream; NULL switches back to a
+ * stream owned by the context (mlt_predict replays its kernel chain from a hipGraph only on an owned stream). */
 int mlt_set_stream(mlt_ctx *ctx, void *hip_stream);
 
 /* Pinned host staging buffers for mlt_predict_batch. */

@@ -11,10 +11,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
     "base": [],
-    "64_16w": ["CFG_64_WCB=1", "CFG_64_WC=2"],
-    "big_16w": ["CFG_BIG_WCB=1", "CFG_BIG_WC=4"],
-    "s2big_16w": ["CFG_S2BIG_WCB=1", "CFG_S2BIG_WC=4"],
-    "s1_rb3": ["CFG_S1_RB=3"],
+    "128_m256": ["CFG_128_WPB=2"],
+    "both_m256": ["CFG_BIG_WPB=2"],
 }
 
 
