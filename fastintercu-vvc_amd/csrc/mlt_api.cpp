@@ -232,7 +232,12 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const int extra_lds = 0;
   const int hw = hout * hout;
   a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
-  const int grid_x = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
+  a.ntiles = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
+  // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
+  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
+  const bool persistent = pc.gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc;
+  const int grid_x = (persistent && a.ntiles > wg_cap) ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "conv3x3_s%d_%dto%d_h%d%s", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");
   const double px = (double)n * hw;

@@ -13,6 +13,7 @@ struct ConvArgs {
   const float *bias;  // folded BN bias per output channel
   const void *res;    // optional residual, same shape as y (NULL: none)
   int n;
+  int ntiles;                  // logical tiles (grid.x may be smaller: workgroups are persistent over tiles)
   int hin_l, hout_l;           // log2 of input / output height (= width)
   int tw_l, th_l, spw_l;       // log2 of tile width, tile height, samples per workgroup
   int ph, pw, rp, half;        // patch rows, cols, row pitch (pixels), parity-split half width

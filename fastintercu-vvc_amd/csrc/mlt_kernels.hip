@@ -86,8 +86,9 @@ __device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // i
 //          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
 //          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
 //          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const ConvArgs a) {
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW>
+// MINW = minimum waves per SIMD (second __launch_bounds__ argument, caps the VGPR allocation); 1 = unconstrained
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
   constexpr int NCHUNK = CIN / KC;
   constexpr int KS = KC / 16;
@@ -122,31 +123,93 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   const int wc = wave % WAVES_C, wp = wave / WAVES_C;
   const int p = lane & 31, h = lane >> 5;
 
-  // ---- tile decode (all powers of two) ----
+  // ---- geometry (all powers of two) ----
   const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l;
   const int TW = 1 << tw_l, TH = 1 << th_l;
   const int hout_l = a.hout_l, hin_l = a.hin_l;
   const int Hin = 1 << hin_l;
   const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;  // tiles per row / column of one sample
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2); give every
-  // XCD a CONTIGUOUS run of tiles so that neighbouring tiles (shared halo rows, same sample) meet in one L2.
-  // Bijective for any grid size (cdna_hip_programming.md T1).
-  int mtile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    mtile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int ctile = blockIdx.y;
-  const int tx = mtile & ((1 << txs_l) - 1);
-  const int ty = (mtile >> txs_l) & ((1 << tys_l) - 1);
-  const int n0 = (mtile >> (txs_l + tys_l)) << spw_l;
   const int PH = a.ph, PW = a.pw, RP = a.rp, HALF = a.half;
   const int m_valid = 1 << (tw_l + th_l + spw_l);
+  const int ctile = blockIdx.y;
+  const int ntiles = a.ntiles;
 
-  // ---- per-lane pixel mapping for this wave's pixel blocks ----
-  int base[WPB];      // LDS byte offset of (pixel, tap (0,0), slot h)
-  int opix[WPB];      // output pixel index (flattened n,y,x) or -1
-  int gidx[WPB];      // gap partial-sum row (sample * nslots + slot) or -1
+  // Workgroups are PERSISTENT over tiles (t = blockIdx.x, += gridDim.x).  XCD-aware order: workgroups are dealt
+  // round-robin over the 8 XCDs (private L2 each); logical tile t maps to a physical tile so that every XCD owns a
+  // CONTIGUOUS run of tiles (neighbouring tiles share halo rows -> same L2).  Bijective for any ntiles (T1).
+  auto tile_decode = [&](int t, int &tx, int &ty, int &n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    tx = mt & ((1 << txs_l) - 1);
+    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
+    n0 = (mt >> (txs_l + tys_l)) << spw_l;
+  };
+
+  // ---- patch loader, split into ISSUE (global -> registers, asynchronous) and COMMIT (registers -> LDS) so that
+  // the loads of the NEXT stage (next channel chunk, or the next tile's first chunk) fly while THIS stage computes ----
+  // UN (template): patch items per lane held in registers across a stage; larger patches take the synchronous tail
+  constexpr int PSTEP = NT / SLOTS;                       // pixels advanced per item step; a lane's 16-byte slot is fixed
+  const int slot = tid & (SLOTS - 1);
+  const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
+  const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
+  half8 pv[UN], pvl[NSPLIT == 2 ? UN : 1];
+  int pdst[UN];  // LDS byte offset; bit 30 set: zero-fill (outside the picture / batch); -1: no item
+  // Branch-free: every load is issued (from a clamped, always-valid address, DISTINCT per lane and workgroup -- never one
+  // shared hot line) before any result is used; a conditional load would be waited for inside its branch.
+  auto load_item = [&](int it, int rr, int px, int n0, int iy0, int ix0, int chunk, half8 &v, half8 &vl, int &dst, bool &live) {
+    const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+    dst = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
+    live = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+    const size_t safe_off = ((((size_t)n0 << hin_l) << hin_l) * CIN) + (size_t)((tid * 8) & ((CIN << (2 * hin_l)) - 1) & ~7);
+    const size_t off = live ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : safe_off;
+    v = *(const half8 *)((const _Float16 *)a.x + off);
+    if constexpr (NSPLIT == 2) vl = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
+  };
+  auto issue_patch = [&](int t, int chunk) {
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
+    int rr = udiv_magic(tid / SLOTS, a.pw_magic), px = tid / SLOTS - rr * PW;  // rr = row counter over (sample, py)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      half8 dummy;
+      bool live;
+      load_item(tid + u * NT, rr, px, n0, iy0, ix0, chunk, pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : dummy, pdst[u], live);
+      if (!live && pdst[u] >= 0) pdst[u] |= 1 << 30;
+      px += step_x; rr += step_r;
+      if (px >= PW) { px -= PW; ++rr; }
+    }
+  };
+  auto put_item = [&](half8 v, half8 vl, int dst, bool live) {
+    if (!live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+    }
+    if (dst >= 0) {
+      *(half8 *)(patch + dst) = v;
+      if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst) = vl;
+    }
+  };
+  auto commit_patch = [&](int t, int chunk) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) put_item(pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : pv[u], pdst[u] < 0 ? -1 : (pdst[u] & ~(1 << 30)), !(pdst[u] & (1 << 30)));
+    if (patch_items > UN * NT) {  // oversized patch (tiny maps, many samples per tile): the rest synchronously
+      int tx, ty, n0;
+      tile_decode(t, tx, ty, n0);
+      const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
+      for (int it = tid + UN * NT; it < patch_items; it += NT) {
+        const int pix = it / SLOTS, rr = udiv_magic(pix, a.pw_magic), px = pix - rr * PW;
+        half8 v, vl;
+        int dst;
+        bool live;
+        load_item(it, rr, px, n0, iy0, ix0, chunk, v, vl, dst, live);
+        put_item(v, vl, dst, live);
+      }
+    }
+  };
+
   // ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32 for the upper half,
   // MI355X_MICROARCH.md LDS table).  With PS/16 odd a group is conflict-free iff its 16 patch-pixel indices are
   // distinct mod 16, so lanes are RANKED such that each group owns 16 consecutive logical pixels: one 16-pixel row
@@ -157,221 +220,266 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
   int pr = p;
   if (rank_lanes) pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
   const bool pair_rows = rank_lanes && tw_l == 3 && th_l >= 3;
+  // tile-independent part of the lane -> pixel map, packed: x[0:5) y[5:10) slot[10:18) sample[18:30) ok[30]
+  int base[WPB], lmap[WPB];
 #pragma unroll
   for (int j = 0; j < WPB; ++j) {
-    int m = (wp * WPB + j) * 32 + pr;
-    bool ok = m < m_valid;
-    int mm = ok ? m : 0;
-    int x = mm & (TW - 1);
+    const int m = (wp * WPB + j) * 32 + pr;
+    const bool ok = m < m_valid;
+    const int mm = ok ? m : 0;
+    const int x = mm & (TW - 1);
     int q = mm >> tw_l;  // row counter over (sample, y)
     if (pair_rows) {
       const int k = q & 7;
       const int kp = STRIDE == 1 ? (((k & 1) << 2) | (k >> 1)) : ((k & 4) | ((k & 1) << 1) | ((k >> 1) & 1));
       q = (q & ~7) | kp;
     }
-    int y = q & (TH - 1), s = q >> th_l;
-    base[j] = ((s * PH + y * STRIDE) * RP + x) * PS + h * 16;
-    int oy = (ty << th_l) + y, ox = (tx << tw_l) + x;
-    ok = ok && (n0 + s) < a.n;
-    opix[j] = ok ? ((((n0 + s) << hout_l) + oy) << hout_l) + ox : -1;
-    const int tile_in_sample = (ty << txs_l) + tx;
-    const int slot = ((tile_in_sample << (tw_l + th_l)) + (mm & ((1 << (tw_l + th_l)) - 1))) >> 5;
-    gidx[j] = ok ? (n0 + s) * a.gap_slots + slot : -1;
+    const int y = q & (TH - 1), sm = q >> th_l;
+    base[j] = ((sm * PH + y * STRIDE) * RP + x) * PS + h * 16;  // LDS byte offset of (pixel, tap (0,0), slot h)
+    lmap[j] = x | (y << 5) | (((mm & ((1 << (tw_l + th_l)) - 1)) >> 5) << 10) | (sm << 18) | ((ok ? 1 : 0) << 30);
   }
 
-  float16v acc[WCB][WPB];
-  float16v acc_sc[SCW][SPB];
-#pragma unroll
-  for (int i = 0; i < WCB; ++i)
-#pragma unroll
-    for (int j = 0; j < WPB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-  for (int i = 0; i < SCW; ++i)
-#pragma unroll
-    for (int j = 0; j < SPB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
-
   const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
-  const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
+  auto issue_step = [&](int chunk, int g, int buf) {
+    const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
+    char *dst = wring + buf * NSPLIT * WCHUNK;
+    // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
+    // its own re-copies the last piece (same bytes to the same place: benign)
+#pragma unroll
+    for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+      for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
+        int pi = wave + k * NW;
+        pi = pi < NPIECE ? pi : NPIECE - 1;
+        glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
+      }
+  };
+  // weights that fit one step and one chunk stay resident in LDS for the life of the (persistent) workgroup
+  constexpr bool W_RESIDENT = NG == 1 && NCHUNK == 1;
+  // Cross-stage prefetch keeps ~UN*4 + 16 more VGPRs live through the MFMA loop.  It pays where the loop is short and
+  // there is no weight ring competing for registers / the vmcnt queue (the 32-channel layers, measured 0.70 -> 0.50 ms);
+  // the ring kernels lose more occupancy than they gain and load each stage's patch right before committing it.
+  constexpr bool PREFETCH = W_RESIDENT;
+  // Persistence (several tiles per workgroup) only where it pays: a real tile loop makes the compiler keep far more state
+  // live (64@32: 79 -> 168 VGPRs, 2 -> 1 workgroups per CU).  Ring kernels run exactly one tile per workgroup (grid.x = ntiles).
+  constexpr bool PERSIST = W_RESIDENT;
+  if constexpr (W_RESIDENT) issue_step(0, 0, 0);
 
-  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk's patch / weights
-    {
-      // ---- stage the input patch chunk: global (16 B / lane) -> LDS, UN independent loads in flight per lane ----
-      const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
-      constexpr int UN = (STRIDE == 2 ? 10 : 6) / NSPLIT;  // loads in flight per lane: one round trip for the usual patch
-      // masked lanes (halo outside the picture, loop tail) still load -- from a valid address that is DISTINCT per lane
-      // and per workgroup (inside this tile's first sample), never from one shared location (that would hot-spot a line)
-      const size_t safe_off = ((((size_t)n0 << hin_l) << hin_l) * CIN) + (size_t)((tid * 8) & ((CIN << (2 * hin_l)) - 1) & ~7);
-      constexpr int PSTEP = NT / SLOTS;  // pixels advanced per item step; the 16-byte slot of a lane is fixed
-      const int slot = tid & (SLOTS - 1);
-      const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
-      int rr = udiv_magic(tid / SLOTS, a.pw_magic), px = tid / SLOTS - rr * PW;  // rr = row counter over (sample, py)
-      for (int it0 = tid; it0 < patch_items; it0 += UN * NT) {
-        // Branch-free: every load is issued (from a clamped, always-valid address) before any result is used, so
-        // UN loads per lane are in flight together; a conditional load would be waited for inside its branch.
-        half8 v[UN], vl[UN];
-        int dst[UN];
-        bool live[UN];
+  // residual prefetch registers (16 B per lane and quad pair, see pair16)
+  constexpr int NRES = WCB * WPB * 2 * NSPLIT;  // residual loads per lane
+  uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
+
+  int t = blockIdx.x;
+  if (PREFETCH && t < ntiles) issue_patch(t, 0);
+
+  int lane16 = lane * 16;
+  for (; t < ntiles; t = PERSIST ? t + (int)gridDim.x : ntiles) {
+    // The tile loop must not become a reason to keep every tile-invariant address term in registers: without this the
+    // compiler hoists them all out of the loop (64@32: 79 -> 168 VGPRs, one workgroup per CU instead of two).  Passing the
+    // few base values through an empty asm makes everything derived from them loop-variant again.
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(base[j]));
+    asm volatile("" : "+v"(lane16));
+    int RPt = RP, HALFt = HALF;
+    asm volatile("" : "+s"(RPt), "+s"(HALFt));
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    int opix[WPB];  // output pixel index (flattened n,y,x) or -1
+    int gidx[WPB];  // gap partial-sum row (sample * nslots + slot) or -1
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+      const int lxj = lmap[j] & 31, lyj = (lmap[j] >> 5) & 31, lsl = (lmap[j] >> 10) & 255, lsj = (lmap[j] >> 18) & 4095;
+      const bool ok = (lmap[j] >> 30) && (n0 + lsj) < a.n;
+      const int oy = (ty << th_l) + lyj, ox = (tx << tw_l) + lxj;
+      opix[j] = ok ? ((((n0 + lsj) << hout_l) + oy) << hout_l) + ox : -1;
+      const int tile_in_sample = (ty << txs_l) + tx;
+      gidx[j] = ok ? (n0 + lsj) * a.gap_slots + ((tile_in_sample << (tw_l + th_l)) >> 5) + lsl : -1;
+    }
+    const int t_next = PERSIST ? t + (int)gridDim.x : ntiles;
+
+    float16v acc[WCB][WPB];
+    float16v acc_sc[SCW][SPB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SCW; ++i)
+#pragma unroll
+      for (int j = 0; j < SPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
+
+    // what flies during the LAST weight steps of a chunk: the next stage's patch and, before the epilogue, the residual
+    auto prefetch_next = [&](int chunk) {
+      if constexpr (!PREFETCH) return;
+      if (chunk + 1 < NCHUNK) issue_patch(t, chunk + 1);
+      else if (t_next < ntiles) issue_patch(t_next, 0);
+      else {  // nothing follows: keep the number of outstanding loads identical (the counted waits depend on it)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          const int it = it0 + u * NT;
-          const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
-          const int iy = iy0 + py, ix = ix0 + px;
-          const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-          dst[u] = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
-          live[u] = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-          const size_t off = live[u] ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : safe_off;
-          v[u] = *(const half8 *)((const _Float16 *)a.x + off);
-          if constexpr (NSPLIT == 2) vl[u] = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
-          px += step_x; rr += step_r;
-          if (px >= PW) { px -= PW; ++rr; }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          if (!live[u]) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[u][e] = (_Float16)0.f; if constexpr (NSPLIT == 2) vl[u][e] = (_Float16)0.f; }
-          }
-          if (dst[u] >= 0) {
-            *(half8 *)(patch + dst[u]) = v[u];
-            if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst[u]) = vl[u];
-          }
+          pv[u] = *(const half8 *)((const _Float16 *)a.x + (size_t)(tid & 255) * 8);
+          if constexpr (NSPLIT == 2) pvl[u] = pv[u];
+          pdst[u] = -1;
         }
       }
-    }
-    // ---- weight ring: steps 0..PFD-1 of this chunk (or the only step) ----
-    auto issue_step = [&](int g, int buf) {
-      const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
-      char *dst = wring + buf * NSPLIT * WCHUNK;
-      // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
-      // its own re-copies the last piece (same bytes to the same place: benign)
+      if (W_RESIDENT && chunk + 1 == NCHUNK && a.res) {  // residual reads (uniform branch): clamped address when the pixel is invalid
 #pragma unroll
-      for (int sp = 0; sp < NSPLIT; ++sp)
+        for (int i = 0; i < WCB; ++i)
 #pragma unroll
-        for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
-          int pi = wave + k * NW;
-          pi = pi < NPIECE ? pi : NPIECE - 1;
-          glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
-        }
+          for (int j = 0; j < WPB; ++j) {
+            const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+              if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
+            }
+          }
+      }
     };
-    issue_step(0, 0);
-    if constexpr (NBUF > 1) {
-#pragma unroll
-      for (int d = 1; d < PFD; ++d)
-        if (d < NG) issue_step(d, d);
-      // step 0 must have landed; the PFD-1 younger steps may stay in flight.  LDS-DMA data is ordered for another
-      // wave's ds_read only by the ISSUING wave's vmcnt followed by a barrier; the patch ds_writes need lgkmcnt(0).
-      constexpr int INFL0 = (PFD - 1 < NG - 1 ? PFD - 1 : NG - 1) * PPW;
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL0) : "memory");
-    } else {
-      __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
-    }
+    // loads in flight behind the ring's last counted wait of a chunk (prefetch_next): patch items (+ residual)
+    const int PF_PATCH = UN * NSPLIT;
 
-    int cur_buf = 0;
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-      char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
-      if constexpr (NBUF > 1) {
-        // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
-        if (g + PFD < NG) {
-          int nb = cur_buf + PFD;
-          if (nb >= NBUF) nb -= NBUF;
-          issue_step(g + PFD, nb);
-        }
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      if constexpr (!PREFETCH) issue_patch(t, chunk);
+      commit_patch(t, chunk);  // registers -> LDS (the compiler waits for exactly these loads here)
+      if constexpr (!W_RESIDENT) {
+        issue_step(chunk, 0, 0);
+#pragma unroll
+        for (int d = 1; d < PFD; ++d)
+          if (d < NG) issue_step(chunk, d, d);
       }
-      // Fragment reads run ONE (tap, k-step) ahead of the MFMAs that consume them (register double buffer), so the
-      // ds_read latency of item i+1 hides under the MFMAs of item i instead of serialising read -> wait -> MFMA.
-      auto tap_off = [&](int tt) -> int {
-        const int t = g * GT + tt;
-        if (TAPS != 9) return 0;
-        const int te = (SC && t == TAPS) ? 4 : t;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
-        const int dy = te / 3, dx = te - dy * 3;
-        return STRIDE == 2 ? (dy * RP + (dx & 1) * HALF + (dx >> 1)) * PS : (dy * RP + dx) * PS;
-      };
-      half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
-      auto load_frags = [&](int item, int slot) {
-        const int tt = item / KS, ks = item - tt * KS;
-        const int toff = tap_off(tt);
-#pragma unroll
-        for (int i = 0; i < WCB; ++i) {
-          af[slot][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
-          if constexpr (NSPLIT == 2) afl[slot][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane * 16);
+      if constexpr (NBUF > 1) {
+        // step 0 must have landed; the PFD-1 younger steps may stay in flight.  LDS-DMA data is ordered for another
+        // wave's ds_read only by the ISSUING wave's vmcnt followed by a barrier; the patch ds_writes need lgkmcnt(0).
+        constexpr int INFL0 = (PFD - 1 < NG - 1 ? PFD - 1 : NG - 1) * PPW;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL0) : "memory");
+      } else if constexpr (W_RESIDENT) {
+        // The resident weights' LDS-DMA is older than the first patch loads, so the wait commit_patch needed for those
+        // already covers it.  Only the patch ds_writes must be visible: lgkmcnt(0) + raw barrier -- a __syncthreads()
+        // would add vmcnt(0) and expose the previous tile's epilogue STORES (vmcnt counts stores on CDNA4).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        prefetch_next(chunk);  // single weight step: the whole MFMA phase + epilogue hide these loads
+      } else {
+        __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
+        prefetch_next(chunk);
+      }
+
+      int cur_buf = 0;
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) {
+        char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
+        if constexpr (NBUF > 1) {
+          // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
+          if (g + PFD < NG) {
+            int nb = cur_buf + PFD;
+            if (nb >= NBUF) nb -= NBUF;
+            issue_step(chunk, g + PFD, nb);
+          }
+          // after the LAST weight step of this chunk has been issued: start the next stage's loads (they are younger than
+          // every ring operation still needed, so the counted waits below simply add them)
+          if (g + PFD == NG - 1 || (NG <= PFD && g == 0)) prefetch_next(chunk);
         }
+        // Fragment reads run ONE (tap, k-step) ahead of the MFMAs that consume them (register double buffer), so the
+        // ds_read latency of item i+1 hides under the MFMAs of item i instead of serialising read -> wait -> MFMA.
+        auto tap_off = [&](int tt) -> int {
+          const int tp = g * GT + tt;
+          if (TAPS != 9) return 0;
+          const int te = (SC && tp == TAPS) ? 4 : tp;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+          const int dy = te / 3, dx = te - dy * 3;
+          return STRIDE == 2 ? (dy * RPt + (dx & 1) * HALFt + (dx >> 1)) * PS : (dy * RPt + dx) * PS;
+        };
+        half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
+        auto load_frags = [&](int item, int sl) {
+          const int tt = item / KS, ks = item - tt * KS;
+          const int toff = tap_off(tt);
 #pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          bf[slot][j] = *(const half8 *)(patch + base[j] + toff + ks * 32);
-          if constexpr (NSPLIT == 2) bfl[slot][j] = *(const half8 *)(patch + a.patch_bytes + base[j] + toff + ks * 32);
-        }
-      };
-      load_frags(0, 0);
+          for (int i = 0; i < WCB; ++i) {
+            af[sl][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+            if constexpr (NSPLIT == 2) afl[sl][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+          }
 #pragma unroll
-      for (int item = 0; item < GT * KS; ++item) {
-        const int cur = item & 1;
-        if (item + 1 < GT * KS) load_frags(item + 1, cur ^ 1);
-        const bool is_sc = SC && (g * GT + item / KS) == TAPS;
-        if (is_sc) {
-          if constexpr (SC) {
+          for (int j = 0; j < WPB; ++j) {
+            bf[sl][j] = *(const half8 *)(patch + base[j] + toff + ks * 32);
+            if constexpr (NSPLIT == 2) bfl[sl][j] = *(const half8 *)(patch + a.patch_bytes + base[j] + toff + ks * 32);
+          }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int item = 0; item < GT * KS; ++item) {
+          const int cur = item & 1;
+          if (item + 1 < GT * KS) load_frags(item + 1, cur ^ 1);
+          const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+          if (is_sc) {
+            if constexpr (SC) {
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                  if constexpr (NSPLIT == 2) {
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                  }
+                }
+            }
+          } else {
 #pragma unroll
             for (int i = 0; i < WCB; ++i)
 #pragma unroll
               for (int j = 0; j < WPB; ++j) {
-                acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                 if constexpr (NSPLIT == 2) {
-                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
-                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
               }
           }
-        } else {
-#pragma unroll
-          for (int i = 0; i < WCB; ++i)
-#pragma unroll
-            for (int j = 0; j < WPB; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-              if constexpr (NSPLIT == 2) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-              }
+        }
+        if constexpr (NBUF > 1) {
+          if (g + 1 < NG) {
+            // step g+1 must have landed; steps g+2 .. min(g+PFD, NG-1) may stay in flight, and so may the next stage's
+            // loads once they have been issued (they are younger): counted vmcnt + raw barrier (__syncthreads() would
+            // drain the whole queue with vmcnt(0))
+            const int last = g + PFD < NG - 1 ? g + PFD : NG - 1;
+            const int infl = last - (g + 1);
+            const bool pf_out = PREFETCH && g + PFD >= NG - 1;  // prefetch_next already issued
+            const bool with_res = false;  // ring kernels read the residual in the epilogue (register budget)
+            if (!pf_out) {
+              if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+              else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
+              else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else if (with_res) {  // infl == 0 here: every ring step has been issued before the prefetch
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT + NRES) : "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT) : "memory");
             }
+            if (++cur_buf == NBUF) cur_buf = 0;
+          }
         }
       }
-      if constexpr (NBUF > 1) {
-        if (g + 1 < NG) {
-          // step g+1 must have landed; steps g+2 .. min(g+PFD, NG-1) may stay in flight (counted vmcnt, raw barrier:
-          // __syncthreads() would drain the LDS-DMA queue with vmcnt(0))
-          const int last = g + PFD < NG - 1 ? g + PFD : NG - 1;
-          const int infl = last - (g + 1);
-          if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
-          else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-          if (++cur_buf == NBUF) cur_buf = 0;
-        }
-      }
+      // everyone is done reading this stage's patch / weights before the next commit overwrites them
+      if (chunk + 1 < NCHUNK) __builtin_amdgcn_s_barrier();
     }
-  }
-
+    (void)PF_PATCH;
   // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
-  // residual reads first, all of them, so they are in flight together (and never queue behind the stores);
-  // 16 bytes per lane: lanes 0-31 fetch channels 8q..8q+7, lanes 32-63 channels 8(q+1).. of quad pairs (q, q+1)
-  uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
-  if (a.res) {
+  if constexpr (!W_RESIDENT) {
+    if (a.res) {  // all residual reads together (16 B per lane and quad pair), clamped address when the pixel is invalid
 #pragma unroll
-    for (int i = 0; i < WCB; ++i)
+      for (int i = 0; i < WCB; ++i)
 #pragma unroll
-      for (int j = 0; j < WPB; ++j) {
-        // clamped address (channel offset only when the pixel is invalid): branch-free
-        const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+        for (int j = 0; j < WPB; ++j) {
+          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
-          if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
+          for (int qq = 0; qq < 2; ++qq) {
+            resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+            if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
+          }
         }
-      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
@@ -503,8 +611,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P) void conv_mfma_kernel(const
       }
     }
   }
+    // the next tile's commit overwrites the patch: every wave must be done reading it (and the GAP / stores above
+    // do not touch LDS)
+    if (t_next < ntiles) __builtin_amdgcn_s_barrier();
+  }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // First layer, composed.  The stem conv has neither BN nor ReLU (arch:277-278: out = conv1(x), then layer0), so
@@ -714,9 +825,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
@@ -793,6 +904,15 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 #ifndef CFG_32_WP
 #define CFG_32_WP 8
 #endif
+#ifndef CFG_S1_MINW   // min waves / SIMD of the 64..256-channel stride-1 kernels (VGPR cap)
+#define CFG_S1_MINW 1
+#endif
+#ifndef CFG_S2_MINW
+#define CFG_S2_MINW 1
+#endif
+#ifndef CFG_32_MINW
+#define CFG_32_MINW 1
+#endif
 #ifndef CFG_BIG_WC
 #define CFG_BIG_WC 2
 #endif
@@ -825,24 +945,25 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 }
 
 // RBF / RBE: weight-ring depth (fast / exact).  Must mirror kCfg.
-#define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE)                                    \
+// UNF / UNE: patch items per lane prefetched in registers (fast / exact), sized for the 128x128 model's tiles
+#define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)                                    \
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
-    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF>(a, grid_x, extra_lds, st); \
-    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE>(a, grid_x, extra_lds, st);           \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF, UNF, MWF>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE, UNE, 1>(a, grid_x, extra_lds, st);           \
   }
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2)
-  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2)
-  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
-  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2)
-  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2)
-  CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2)
-  CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2)
-  CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2)
+  CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
+  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
+  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 1, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
+  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
+  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
+  CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2, 5, 3, 1)
+  CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2, 3, 2, 1)
+  CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2, 5, 3, 1)
   return hipErrorInvalidValue;
 }
 

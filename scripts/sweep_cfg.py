@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
-    "base": [],
-    "128_m256": ["CFG_128_WPB=2"],
-    "both_m256": ["CFG_BIG_WPB=2"],
+    "s1mw4": [],
+    "s1mw3": ["CFG_S1_MINW=3"],
+    "s1mw1": ["CFG_S1_MINW=1"],
+    "s2mw3": ["CFG_S2_MINW=3"],
+    "32mw3": ["CFG_32_MINW=3"],
+    "32mw4": ["CFG_32_MINW=4"],
 }
 
 
