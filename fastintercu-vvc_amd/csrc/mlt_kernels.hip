@@ -904,6 +904,12 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 #ifndef CFG_32_WP
 #define CFG_32_WP 8
 #endif
+#ifndef CFG_64_GT      // taps per weight step, 64@32 stride-1 (9 = all weights resident in LDS)
+#define CFG_64_GT 9
+#endif
+#ifndef CFG_BIG_GT     // 128@16 / 256@8 stride-1
+#define CFG_BIG_GT 1
+#endif
 #ifndef CFG_S1_MINW   // min waves / SIMD of the 64..256-channel stride-1 kernels (VGPR cap)
 #define CFG_S1_MINW 1
 #endif
@@ -921,11 +927,11 @@ static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
     {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
-    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {1, 1}},
+    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}},
     {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
-    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}},
     {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
-    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {1, 1}},
+    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
     {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
@@ -956,11 +962,11 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
   CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
   CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
-  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 1, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
+  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
   CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
+  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_GT, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
   CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, 1, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
+  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_GT, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2, 5, 3, 1)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2, 3, 2, 1)
   CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2, 5, 3, 1)

@@ -10,12 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
-    "s1mw4": [],
-    "s1mw3": ["CFG_S1_MINW=3"],
-    "s1mw1": ["CFG_S1_MINW=1"],
-    "s2mw3": ["CFG_S2_MINW=3"],
-    "32mw3": ["CFG_32_MINW=3"],
-    "32mw4": ["CFG_32_MINW=4"],
+    "base": [],
+    "64_resident": ["CFG_64_GT=9"],
+    "64_gt3": ["CFG_64_GT=3"],
+    "big_gt3": ["CFG_BIG_GT=3"],
+    "64res_wpb2_4w": ["CFG_64_GT=9", "CFG_64_WPB=2", "CFG_64_WP=4"],
 }
 
 
