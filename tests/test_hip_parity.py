@@ -199,3 +199,66 @@ def test_cpp_call_site_demo_matches_python_binding(gpu, tmp_path):
     assert f"predictedSplitMode = {split} " in out.stdout, out.stdout
     got = [float(v) for v in out.stdout.split("=")[-1].split()]
     assert np.allclose(got, logits[5:9], atol=2e-4), (got, logits[5:9])
+
+
+def test_full_batch_4096_properties(gpu):
+    """BASELINE.json's full size (4096 x 128x128): size-independent properties, all bit-exact --
+    (1) run-to-run determinism, (2) permutation equivariance (a CU's result does not depend on its batch position or
+    neighbours), (3) invariance to the internal chunking, (4) device-pointer entry == host-pointer entry --
+    plus a random 24-CU spot check of that same batch against the oracle."""
+    import os
+    import torch
+    from oracle import Oracle
+    pkg = gpu
+    n, size = 4096, 128
+    blob = pkg.weights.synthetic_blob(0, 10)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 0xBEEF)
+    poc, qp = pkg.synth.make_scalars(n, 0xBEEF)
+    m = _ctx(pkg, size, blob)
+    s0, l0 = m.predict_batch(org, pred, poc, qp)
+    s1, l1 = m.predict_batch(org, pred, poc, qp)
+    assert np.array_equal(l0, l1) and np.array_equal(s0, s1), "not deterministic"
+    perm = np.random.RandomState(7).permutation(n)
+    sp, lp = m.predict_batch(org[perm], pred[perm], poc[perm], qp[perm])
+    assert np.array_equal(lp, l0[perm]) and np.array_equal(sp, s0[perm]), "result depends on batch position"
+    # device-pointer entry (what bench.py times)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+    d_split = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    d_logits = torch.zeros((n, 9), dtype=torch.float32, device=dev)
+    m.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_logits.data_ptr())
+    m.synchronize()
+    assert np.array_equal(d_logits.cpu().numpy(), l0) and np.array_equal(d_split.cpu().numpy(), s0)
+    m.close()
+    os.environ["MLT_CHUNK"] = "1000"  # ragged chunks: 1000,1000,1000,1000,96
+    try:
+        mc = _ctx(pkg, size, blob)
+        sc, lc = mc.predict_batch(org, pred, poc, qp)
+        mc.close()
+    finally:
+        del os.environ["MLT_CHUNK"]
+    assert np.array_equal(lc, l0) and np.array_equal(sc, s0), "result depends on chunking"
+    idx = np.sort(np.random.RandomState(11).choice(n, 24, replace=False))
+    ref, ref_split = Oracle(blob).forward(org[idx], pred[idx], poc[idx], qp[idx], threads=8)
+    err = float(np.abs(l0[idx] - ref).max())
+    print("full batch: max|dlogit| on 24 random CUs", err)
+    assert err <= LOGIT_TOL
+    sl = head_slices([2, 3, 4])[2]
+    for k, i in enumerate(idx):
+        if decisive(ref[k], sl, 2 * LOGIT_TOL):
+            assert s0[i] == ref_split[k]
+
+
+def test_empty_and_single_batches(gpu):
+    pkg = gpu
+    blob = pkg.weights.synthetic_blob(1, 10)
+    m = _ctx(pkg, 32, blob)
+    org, pred = pkg.synth.make_patches(32, 3, 9)
+    poc, qp = pkg.synth.make_scalars(3, 9)
+    s_e, l_e = m.predict_batch(org[:0], pred[:0], poc[:0], qp[:0])
+    assert s_e.shape == (0,) and l_e.shape == (0, 15)
+    s3, l3 = m.predict_batch(org, pred, poc, qp)
+    for i in range(3):
+        s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        assert s1 == s3[i] and np.array_equal(l1, l3[i])
+    m.close()
