@@ -287,6 +287,25 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
   return debug_dump(ctx, (std::string(name) + "_sc").c_str(), y_sc, (size_t)px * 32 * 2);
 }
 
+// Fused identity BasicBlock of the 32-channel stage (fast arithmetic, H >= 32): conv1 -> LDS -> conv2 + residual.
+int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, void *y) {
+  Block32Args a{};
+  a.x = x; a.y = y; a.w1 = B.conv1.d_w; a.w2 = B.conv2.d_w; a.bias1 = B.conv1.d_bias; a.bias2 = B.conv2.d_bias;
+  a.n = n; a.h_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
+  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
+  char name[48];
+  std::snprintf(name, sizeof name, "block_s1_32_h%d(conv1+conv2)", h);
+  const double px = (double)n * h * h;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin(name, 2.0 * px * 32 * 32 * 9 * 2, px * 32 * 2 * 2 + 2.0 * 18 * 1024, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_block32(a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
+}
+
 // One chunk of n CUs through the whole network, everything on ctx->stream.
 int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs,
                 long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
@@ -337,6 +356,13 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
     // block 1 (identity shortcut)
     mlt::Block &B1 = m.blocks[s][1];
+    static const bool no_fuse = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+    if (s == 0 && !m.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
+      if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
+      cur = outs[s];
+      h = hout;
+      continue;
+    }
     io = ConvIO();
     io.x = pool[2]; io.y = pool[3]; io.relu = true;
     io.x_lo = io.y_lo = lo_st;

@@ -46,6 +46,14 @@ struct Stem5Args {
   uint32_t rw_magic, rh_magic;
 };
 
+struct Block32Args {
+  const void *x;               // block input  [n][H][H][32] fp16 (also the residual)
+  void *y;                     // block output [n][H][H][32] fp16
+  const void *w1, *w2;         // packed fp16 weights of conv1 / conv2 (18 KiB each, fast mode layout)
+  const float *bias1, *bias2;  // folded BN biases
+  int n, h_l, ntiles;          // H = 1 << h_l (>= 32); tiles of 16 x 32 output pixels
+};
+
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
   int slots[MLT_MAX_HEADS_K];
@@ -61,4 +69,5 @@ struct HeadArgs {
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
+hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

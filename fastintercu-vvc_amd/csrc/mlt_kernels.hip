@@ -617,6 +617,151 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused identity BasicBlock for the 32-channel stage (layer0.1, arch:52-57 with identity shortcut):
+//     out = relu( bn2(conv2( relu(bn1(conv1(x))) )) + x )
+// One workgroup owns a 16 x 32 output tile: the input patch (tile + 2-pixel halo) is staged once, conv1 is evaluated on
+// tile + 1-pixel halo and its activation goes to LDS as fp16 (zero outside the picture = conv2's padding), conv2 reads it
+// from LDS and takes the residual from the input patch that is still in LDS.  Per CU this reads x once (1.4x with halo,
+// mostly L2 hits) and writes out once: 616 KiB instead of the 1280 KiB of two separate conv launches; the intermediate
+// activation never touches HBM.  Both weight sets (2 x 18 KiB) stay resident in LDS; workgroups are persistent over tiles
+// and prefetch the next tile's patch into registers while computing (issue-early / commit-late).  Fast arithmetic only.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
+  constexpr int TH = 16, TW = 32, C = 32, PS = 80;          // pixel stride: 64 B of channels + 16 B pad (PS/16 odd)
+  constexpr int XH = TH + 4, XW = TW + 4, T_H = TH + 2, T_W = TW + 2;
+  constexpr int XBYTES = XH * XW * PS, TBYTES = T_H * T_W * PS, WBYTES = 18 * 1024;
+  constexpr int NT = 512, NW = 8, UN = 6;                   // 20*36*4 = 2880 patch items <= 6 * 512
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *X = smem, *T = smem + XBYTES, *W1 = T + TBYTES, *W2 = W1 + WBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int h_l = a.h_l, H = 1 << h_l;
+  const int txs_l = h_l - 5, tys_l = h_l - 4;               // tiles per row (H/32) and per column (H/16)
+  const int ntiles = a.ntiles;
+  auto tile_decode = [&](int t, int &tx, int &ty, int &n) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;  // XCD-contiguous tile order (see conv_mfma_kernel)
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    tx = mt & ((1 << txs_l) - 1);
+    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
+    n = mt >> (txs_l + tys_l);
+  };
+  // resident weights: 18 one-KiB LDS-DMA pieces per conv
+  for (int pi = wave; pi < 18; pi += NW) {
+    glds16((const char *)a.w1 + pi * 1024 + lane * 16, W1 + pi * 1024);
+    glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
+  }
+  // ---- input patch: issue (global -> registers) / commit (registers -> LDS) ----
+  half8 pv[UN];
+  int pdst[UN];  // LDS byte offset, bit 30: zero-fill, -1: none
+  auto issue_patch = [&](int t) {
+    int tx, ty, n;
+    tile_decode(t, tx, ty, n);
+    const int iy0 = ty * TH - 2, ix0 = tx * TW - 2;
+    const size_t nbase = (((size_t)n << h_l) << h_l) * C;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int it = tid + u * NT, slot = it & 3, pix = it >> 2;
+      const int row = pix / XW, col = pix - row * XW;
+      const int iy = iy0 + row, ix = ix0 + col;
+      const bool in_items = pix < XH * XW;
+      const bool live = in_items && iy >= 0 && iy < H && ix >= 0 && ix < H;
+      pdst[u] = in_items ? ((row * XW + col) * PS + slot * 16) | (live ? 0 : 1 << 30) : -1;
+      // masked lanes load a valid, lane-distinct address inside this sample (never one shared hot line)
+      const size_t off = live ? nbase + ((((size_t)iy << h_l) + ix) * C) + slot * 8 : nbase + (size_t)((tid * 8) & ((C << (2 * h_l)) - 8));
+      pv[u] = *(const half8 *)((const _Float16 *)a.x + off);
+    }
+  };
+  auto commit_patch = [&]() {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      half8 v = pv[u];
+      if (pdst[u] & (1 << 30)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+      }
+      if (pdst[u] >= 0) *(half8 *)(X + (pdst[u] & ~(1 << 30))) = v;
+    }
+  };
+  // one 32-pixel block of a 3x3 conv: A fragments from the resident weights, B fragments from an LDS patch
+  auto conv_block = [&](const char *Wres, const char *patch, int base, int pitch) -> float16v {
+    float16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    half8 af[2], bf[2];
+    af[0] = *(const half8 *)(Wres + lane * 16);
+    bf[0] = *(const half8 *)(patch + base);
+#pragma unroll
+    for (int item = 0; item < 18; ++item) {  // 9 taps x 2 k-steps, fragment reads one item ahead of the MFMAs
+      const int cur = item & 1;
+      if (item + 1 < 18) {
+        const int tp = (item + 1) >> 1, ks = (item + 1) & 1, dy = tp / 3, dx = tp - dy * 3;
+        af[cur ^ 1] = *(const half8 *)(Wres + (item + 1) * 1024 + lane * 16);
+        bf[cur ^ 1] = *(const half8 *)(patch + base + (dy * pitch + dx) * PS + ks * 32);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur], bf[cur], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) issue_patch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    int tx, ty, n;
+    tile_decode(t, tx, ty, n);
+    commit_patch();  // waits for exactly the prefetched loads (the resident weights' DMA is older, hence landed too)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int t_next = t + gridDim.x;
+    if (t_next < ntiles) issue_patch(t_next);
+
+    // ---- conv1 + bn1 + relu on tile + 1-pixel halo (18 x 34 = 612 pixels = 20 blocks) -> T (fp16, LDS) ----
+    for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
+      const int m = pb * 32 + p;
+      const bool ok = m < T_H * T_W;
+      const int mm = ok ? m : 0;
+      const int y1 = mm / T_W, x1 = mm - y1 * T_W;
+      const float16v acc = conv_block(W1, X, (y1 * XW + x1) * PS + h * 16, XW);
+      // positions outside the picture are conv2's zero padding, not conv1 of padded input
+      const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;
+      if (ok) {
+        char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4v b = *(const float4v *)(a.bias1 + 4 * h + 8 * q);
+          half4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] + b[e], 0.f) : (_Float16)0.f;
+          *(half4 *)(dst + 16 * q) = o;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- conv2 + bn2 + residual (input patch centre) + relu on the 16 x 32 tile (16 blocks) -> HBM ----
+    for (int pb = wave; pb < TH * TW / 32; pb += NW) {
+      const int y = pb, x = p;  // one tile row per block (TW = 32)
+      const float16v acc = conv_block(W2, T, (y * T_W + x) * PS + h * 16, T_W);
+      const char *rsrc = X + ((y + 2) * XW + x + 2) * PS + 8 * h;
+      half4 hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4v b = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
+        const half4 r = *(const half4 *)(rsrc + 16 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b[e] + (float)r[e], 0.f);
+      }
+      const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * C + (size_t)(tx * TW + x) * C + 8 * h;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
+    }
+    // the next commit overwrites X, the next conv1 overwrites T
+    if (t_next < ntiles) __builtin_amdgcn_s_barrier();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // First layer, composed.  The stem conv has neither BN nor ReLU (arch:277-278: out = conv1(x), then layer0), so
 //   t  = relu(bn1(conv3x3_s2(stem(x))))   is ONE linear 5x5 stride-2 conv of the 2 raw channels (+ bias, ReLU), and
@@ -976,6 +1121,18 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const Conv
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st) {
   if (exact) hipLaunchKernelGGL(stem5_kernel<2>, dim3(grid_x), dim3(256), lds, st, a);
   else hipLaunchKernelGGL(stem5_kernel<1>, dim3(grid_x), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) {
+  constexpr int lds = (20 * 36 + 18 * 34) * 80 + 2 * 18 * 1024;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)block32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(block32_kernel, dim3(grid_x), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
