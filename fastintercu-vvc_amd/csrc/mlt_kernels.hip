@@ -19,6 +19,11 @@
 
 #include "mlt_kernels.h"
 
+// build-time tuning knob (scripts/sweep_cfg.py)
+#ifndef CFG_BIAS_EARLY  // 1: bias loads before the MFMA phase (latency hidden, +16..32 VGPRs); 0: at the epilogue
+#define CFG_BIAS_EARLY 1
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -296,6 +301,22 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       gidx[j] = ok ? (n0 + lsj) * a.gap_slots + ((tile_in_sample << (tw_l + th_l)) >> 5) + lsl : -1;
     }
     const int t_next = PERSIST ? t + (int)gridDim.x : ntiles;
+    // folded BN biases of this lane's output channels: issued here so the loads fly under the staging / MFMA phase
+    // (a load placed in the epilogue is waited for on the spot)
+    float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
+    auto load_biases = [&]() {
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+          if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+        }
+    };
+    // early (latency hidden under the MFMA phase, +16..32 live VGPRs) where registers are not the occupancy limiter;
+    // the stride-1 ring kernels load them at the epilogue (measured: 128@16 0.41 vs 0.48 ms)
+    constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || SC);
+    if constexpr (BIAS_EARLY) load_biases();
 
     float16v acc[WCB][WPB];
     float16v acc_sc[SCW][SPB];
@@ -466,6 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
     (void)PF_PATCH;
   // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
+  if constexpr (!BIAS_EARLY) load_biases();
   if constexpr (!W_RESIDENT) {
     if (a.res) {  // all residual reads together (16 B per lane and quad pair), clamped address when the pixel is invalid
 #pragma unroll
@@ -484,12 +506,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
     const int cbase = ctile * CT + (wc * WCB + i) * 32 + 4 * h;
-    float4v bq[4], bsq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bq[q] = *(const float4v *)(a.bias + cbase + 8 * q);
-      if constexpr (SC) bsq[q] = *(const float4v *)(a.bias_sc + cbase + 8 * q);
-    }
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
       const bool ok = opix[j] >= 0;
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
           const int q = 2 * qq + k;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float x = acc[i][j][4 * q + e] * a.acc_scale + bq[q][e];
+            float x = acc[i][j][4 * q + e] * a.acc_scale + bq[i][q][e];
             if (a.res) {
               x += (float)(k ? rb[e] : ra[e]);
               if constexpr (NSPLIT == 2) x += (float)(k ? rlb[e] : rla[e]);
@@ -518,7 +534,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
             hq[q][e] = (_Float16)x;
             hl[q][e] = (_Float16)(x - (float)hq[q][e]);
             if constexpr (SC) {
-              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[q][e];
+              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[i][q][e];
               sq[q][e] = (_Float16)vs;
               sl[q][e] = (_Float16)(vs - (float)sq[q][e]);
             }
@@ -685,26 +701,40 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
       if (pdst[u] >= 0) *(half8 *)(X + (pdst[u] & ~(1 << 30))) = v;
     }
   };
-  // one 32-pixel block of a 3x3 conv: A fragments from the resident weights, B fragments from an LDS patch
-  auto conv_block = [&](const char *Wres, const char *patch, int base, int pitch) -> float16v {
+  // One 32-pixel block of a 3x3 conv.  The conv's 18 weight (A) fragments sit in REGISTERS for the whole phase (LDS
+  // capacity already limits this kernel to one workgroup per CU, so VGPRs are free): only the activation (B) fragments
+  // are read from LDS, 1 ds_read_b128 per MFMA instead of 2, software-pipelined one item ahead.
+  half8 wf[18];
+  auto load_weights = [&](const char *Wres) {
+#pragma unroll
+    for (int item = 0; item < 18; ++item) wf[item] = *(const half8 *)(Wres + item * 1024 + lane * 16);
+  };
+  auto conv_block = [&](const char *patch, int base, int pitch) -> float16v {
     float16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    half8 af[2], bf[2];
-    af[0] = *(const half8 *)(Wres + lane * 16);
-    bf[0] = *(const half8 *)(patch + base);
+    auto frag = [&](int item) -> half8 {
+      const int tp = item >> 1, ks = item & 1, dy = tp / 3, dx = tp - dy * 3;
+      return *(const half8 *)(patch + base + (dy * pitch + dx) * PS + ks * 32);
+    };
+    half8 bf[3];  // activation fragments run TWO items ahead of the MFMA that consumes them (LDS latency ~ 2 MFMAs)
+    bf[0] = frag(0);
+    bf[1] = frag(1);
 #pragma unroll
-    for (int item = 0; item < 18; ++item) {  // 9 taps x 2 k-steps, fragment reads one item ahead of the MFMAs
-      const int cur = item & 1;
-      if (item + 1 < 18) {
-        const int tp = (item + 1) >> 1, ks = (item + 1) & 1, dy = tp / 3, dx = tp - dy * 3;
-        af[cur ^ 1] = *(const half8 *)(Wres + (item + 1) * 1024 + lane * 16);
-        bf[cur ^ 1] = *(const half8 *)(patch + base + (dy * pitch + dx) * PS + ks * 32);
-      }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur], bf[cur], acc, 0, 0, 0);
+    for (int item = 0; item < 18; ++item) {  // 9 taps x 2 k-steps
+      if (item + 2 < 18) bf[(item + 2) % 3] = frag(item + 2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[item], bf[item % 3], acc, 0, 0, 0);
     }
     return acc;
   };
+  // folded BN biases of this lane's 16 output channels, once per kernel (a load inside the per-block epilogue is waited
+  // for on the spot: four serialised memory round trips per 32-pixel block)
+  float4v b1r[4], b2r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b1r[q] = *(const float4v *)(a.bias1 + 4 * h + 8 * q);
+    b2r[q] = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
+  }
 
   int t = blockIdx.x;
   if (t < ntiles) issue_patch(t);
@@ -717,12 +747,13 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
     if (t_next < ntiles) issue_patch(t_next);
 
     // ---- conv1 + bn1 + relu on tile + 1-pixel halo (18 x 34 = 612 pixels = 20 blocks) -> T (fp16, LDS) ----
+    load_weights(W1);
     for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
       const int m = pb * 32 + p;
       const bool ok = m < T_H * T_W;
       const int mm = ok ? m : 0;
       const int y1 = mm / T_W, x1 = mm - y1 * T_W;
-      const float16v acc = conv_block(W1, X, (y1 * XW + x1) * PS + h * 16, XW);
+      const float16v acc = conv_block(X, (y1 * XW + x1) * PS + h * 16, XW);
       // positions outside the picture are conv2's zero padding, not conv1 of padded input
       const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;
       const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;
@@ -730,10 +761,9 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
         char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4v b = *(const float4v *)(a.bias1 + 4 * h + 8 * q);
           half4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] + b[e], 0.f) : (_Float16)0.f;
+          for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] + b1r[q][e], 0.f) : (_Float16)0.f;
           *(half4 *)(dst + 16 * q) = o;
         }
       }
@@ -741,17 +771,17 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- conv2 + bn2 + residual (input patch centre) + relu on the 16 x 32 tile (16 blocks) -> HBM ----
+    load_weights(W2);
     for (int pb = wave; pb < TH * TW / 32; pb += NW) {
       const int y = pb, x = p;  // one tile row per block (TW = 32)
-      const float16v acc = conv_block(W2, T, (y * T_W + x) * PS + h * 16, T_W);
+      const float16v acc = conv_block(T, (y * T_W + x) * PS + h * 16, T_W);
       const char *rsrc = X + ((y + 2) * XW + x + 2) * PS + 8 * h;
       half4 hq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4v b = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
         const half4 r = *(const half4 *)(rsrc + 16 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b[e] + (float)r[e], 0.f);
+        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b2r[q][e] + (float)r[e], 0.f);
       }
       const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * C + (size_t)(tx * TW + x) * C + 8 * h;
 #pragma unroll
@@ -837,6 +867,13 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
   }
   __syncthreads();
 
+  // biases once per kernel (a load inside the per-block epilogue would be waited for on the spot)
+  float4v sb1[4], sbs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sb1[q] = *(const float4v *)(a.bias + 4 * h + 8 * q);
+    sbs[q] = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
+  }
   // raw offset of tap (u, v) relative to the pixel origin (row 2y, column 2x): columns are parity-split
   auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
   auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
@@ -895,11 +932,10 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
       half4 t[4], tl[4], c[4], cl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4v b1 = *(const float4v *)(a.bias + 4 * h + 8 * q), bs = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float vt = fmaxf(acc[4 * q + e] * a.acc_scale + b1[e], 0.f);  // relu(bn1(conv1(stem)))
-          const float vc = accs[4 * q + e] * a.acc_scale + bs[e];             // bn(shortcut conv(stem))
+          const float vt = fmaxf(acc[4 * q + e] * a.acc_scale + sb1[q][e], 0.f);  // relu(bn1(conv1(stem)))
+          const float vc = accs[4 * q + e] * a.acc_scale + sbs[q][e];             // bn(shortcut conv(stem))
           t[q][e] = (_Float16)vt; tl[q][e] = (_Float16)(vt - (float)t[q][e]);
           c[q][e] = (_Float16)vc; cl[q][e] = (_Float16)(vc - (float)c[q][e]);
         }

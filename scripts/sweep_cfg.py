@@ -10,11 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
-    "base": [],
-    "64_resident": ["CFG_64_GT=9"],
-    "64_gt3": ["CFG_64_GT=3"],
-    "big_gt3": ["CFG_BIG_GT=3"],
-    "64res_wpb2_4w": ["CFG_64_GT=9", "CFG_64_WPB=2", "CFG_64_WP=4"],
+    "bias_early": [],
+    "bias_late": ["CFG_BIAS_EARLY=0"],
+    "bias_early2": [],
+    "bias_late2": ["CFG_BIAS_EARLY=0"],
 }
 
 
