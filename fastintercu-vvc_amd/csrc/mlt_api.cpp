@@ -287,6 +287,29 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
   return debug_dump(ctx, (std::string(name) + "_sc").c_str(), y_sc, (size_t)px * 32 * 2);
 }
 
+// Whole layer0.0 (composed first layer + conv2 + shortcut + relu) from the raw planes in one kernel (fast, H >= 32).
+int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
+                   long pred_rs, long pred_cs, void *y) {
+  const int h = S / 2;
+  const mlt::PackedConv &c2 = m.blocks[0][0].conv2;
+  StemBlockArgs a{};
+  a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
+  a.w = m.stem.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
+  a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
+  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+  const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
+  char name[48];
+  std::snprintf(name, sizeof name, "stem+block_s2_2to32_h%d(layer0.0)", h);
+  const double px = (double)n * h * h;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18 + 288), (double)n * S * S * 4 + px * 32 * 2, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_stem_block(a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
+}
+
 // Fused identity BasicBlock of the 32-channel stage (fast arithmetic, H >= 32): conv1 -> LDS -> conv2 + residual.
 int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, void *y) {
   Block32Args a{};
@@ -346,14 +369,21 @@ int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long o
     ConvIO io;
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
     io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
-    if (s == 0) {
+    static const bool no_fuse0 = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+    const bool fused_b0 = s == 0 && !m.exact && ho >= 32 && !no_fuse0;
+    if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;
-      if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
-    } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
-    io = ConvIO();
-    io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
-    io.x_lo = io.y_lo = io.res_lo = lo_st;
-    if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
+      if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2]))) return rc;
+    } else {
+      if (s == 0) {
+        hout = ho;
+        if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
+      } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      io = ConvIO();
+      io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
+      io.x_lo = io.y_lo = io.res_lo = lo_st;
+      if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
+    }
     // block 1 (identity shortcut)
     mlt::Block &B1 = m.blocks[s][1];
     static const bool no_fuse = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;

@@ -54,6 +54,17 @@ struct Block32Args {
   int n, h_l, ntiles;          // H = 1 << h_l (>= 32); tiles of 16 x 32 output pixels
 };
 
+struct StemBlockArgs {
+  const int16_t *org, *pred;   // Pel planes
+  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
+  const void *w;               // composed first-layer weights (Stem5Args.w layout, fast plane)
+  const void *w2;              // layer0.0.conv2 packed weights (18 KiB)
+  const float *bias, *bias_sc, *bias2;
+  void *y;                     // b0 [n][H][H][32] fp16
+  float acc_scale;             // composed-weight storage scale (2^-12)
+  int n, hout_l, ntiles;       // H = 1 << hout_l (>= 32), picture 2H x 2H; tiles of 16 x 32 output pixels
+};
+
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
   int slots[MLT_MAX_HEADS_K];
@@ -70,4 +81,5 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const Conv
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
 hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -959,6 +959,194 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Whole first BasicBlock (layer0.0) from the raw Pel planes, fast arithmetic, output maps >= 32 x 32:
+//     t  = relu(bn1(conv1(stem x)))         composed 5x5 stride-2 conv + border slots   (see stem5_kernel)
+//     b0 = relu(bn2(conv2(t)) + bn(shortcut(stem x)))
+// One workgroup owns a 16 x 32 tile of b0: the raw (org, |org-pred|) patch for tile + 1-pixel halo of t is staged in LDS
+// (39 x 71 pixels, 11 KiB), t is evaluated on 18 x 34 pixels and kept in LDS as fp16 (zero outside the picture = conv2's
+// padding), conv2 reads it from LDS, and the shortcut is evaluated for the same pixel block and added in fp32 (it is never
+// rounded to fp16).  HBM sees 64 KiB of Pel planes in and 256 KiB of b0 out per 128x128 CU -- t and sc (2 x 256 KiB written
+// and read back by the two-kernel form) never exist.  conv2's weights are resident in LDS (and in registers during the
+// phase), the composed first-layer weights live in registers; persistent workgroups prefetch the next raw patch.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) {
+  constexpr int TH = 16, TW = 32, PS = 80;
+  constexpr int T_H = TH + 2, T_W = TW + 2;                 // t region: tile + 1-pixel halo
+  constexpr int RH = 2 * T_H + 3, RW = 2 * T_W + 3;         // raw patch 39 x 71
+  constexpr int HW = (RW + 1) / 2, RP = 2 * HW;             // parity-split columns, row pitch 72
+  constexpr int RAWBYTES = (RH * RP * 4 + 15) / 16 * 16, TBYTES = T_H * T_W * PS;
+  constexpr int NT = 512, NW = 8, UR = 6;                   // 39*71 = 2769 raw pixels <= 6 * 512
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *raw = (uint32_t *)smem;
+  char *T = smem + RAWBYTES, *W2 = T + TBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 31, h = lane >> 5;
+  const int h_l = a.hout_l, H = 1 << h_l, S = 2 * H;        // output map H x H, picture S x S
+  const int txs_l = h_l - 5, tys_l = h_l - 4;
+  const int ntiles = a.ntiles;
+  auto tile_decode = [&](int t, int &tx, int &ty, int &n) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;  // XCD-contiguous tile order
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    tx = mt & ((1 << txs_l) - 1);
+    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
+    n = mt >> (txs_l + tys_l);
+  };
+  for (int pi = wave; pi < 18; pi += NW) glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
+  // composed first-layer weights (5 k-steps for t, 2 for the shortcut) and all biases: registers, once per kernel
+  half8 am[5], as[2];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) am[k] = *(const half8 *)((const char *)a.w + k * 1024 + lane * 16);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) as[k] = *(const half8 *)((const char *)a.w + (5 + k) * 1024 + lane * 16);
+  float4v b1r[4], bsr[4], b2r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b1r[q] = *(const float4v *)(a.bias + 4 * h + 8 * q);
+    bsr[q] = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
+    b2r[q] = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
+  }
+  // ---- raw patch: issue (global -> registers) / commit (registers -> LDS) ----
+  int16_t vo[UR], vp[UR];
+  int rdst[UR];  // dword index in `raw`, bit 30: zero-fill, -1: none
+  auto issue_raw = [&](int t) {
+    int tx, ty, n;
+    tile_decode(t, tx, ty, n);
+    const int iy0 = 2 * (ty * TH - 1) - 2, ix0 = 2 * (tx * TW - 1) - 2;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int it = tid + u * NT;
+      const int ry = it / RW, rx = it - ry * RW;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      const bool in_items = it < RH * RW;
+      const bool live = in_items && iy >= 0 && iy < S && ix >= 0 && ix < S;
+      rdst[u] = in_items ? (ry * RP + (rx & 1) * HW + (rx >> 1)) | (live ? 0 : 1 << 30) : -1;
+      const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + (tid & (S - 1));
+      const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + (tid & (S - 1));
+      vo[u] = a.org[oo];
+      vp[u] = a.pred[po];
+    }
+  };
+  auto commit_raw = [&]() {
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+      if (rdst[u] >= 0) raw[rdst[u] & ~(1 << 30)] = (rdst[u] & (1 << 30)) ? 0u : prep_pair(vo[u], vp[u]);
+  };
+  auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
+  auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
+
+  int t = blockIdx.x;
+  if (t < ntiles) issue_raw(t);
+  for (; t < ntiles; t += gridDim.x) {
+    int tx, ty, n;
+    tile_decode(t, tx, ty, n);
+    commit_raw();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int t_next = t + gridDim.x;
+    if (t_next < ntiles) issue_raw(t_next);
+
+    // ---- phase 1: t on tile + halo (18 x 34 = 612 pixels = 20 blocks), composed 5x5 stride-2 conv -> T (fp16, LDS) ----
+    for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
+      const int m = pb * 32 + p;
+      const bool ok = m < T_H * T_W;
+      const int mm = ok ? m : 0;
+      const int y1 = mm / T_W, x1 = mm - y1 * T_W;
+      const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;  // position in the H x H map
+      const int o = (2 * y1) * RP + x1;                         // window origin = input (2gy-2, 2gx-2)
+      const bool top = gy == 0, left = gx == 0;
+      constexpr int orow0 = 4 * RP;                              // raw row of input row 0 (tiles with ty == 0)
+      auto slot_val = [&](int slot) -> uint32_t {                // K slot of the composed conv (see stem5_kernel)
+        if (slot < 25) return raw[o + main_off(slot)];
+        if (slot < 30) { const uint32_t v = raw[top ? orow0 + x1 + tap(0, slot - 25) : o]; return top ? v : 0u; }
+        if (slot < 35) { const uint32_t v = raw[left ? o + (slot - 30) * RP + 1 : o]; return left ? v : 0u; }
+        if (slot == 35) { const uint32_t v = raw[(top && left) ? orow0 + 2 : o]; return (top && left) ? v : 0u; }
+        return 0u;
+      };
+      float16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        half8 b;
+        uint32_t *bw = (uint32_t *)&b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ks < 3) bw[e] = raw[o + (h ? main_off(8 * ks + 4 + e) : main_off(8 * ks + e))];
+          else { const uint32_t v0 = slot_val(8 * ks + e), v1 = slot_val(8 * ks + 4 + e); bw[e] = h ? v1 : v0; }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ks], b, acc, 0, 0, 0);
+      }
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;  // outside: conv2's zero padding
+      if (ok) {
+        char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] * a.acc_scale + b1r[q][e], 0.f) : (_Float16)0.f;
+          *(half4 *)(dst + 16 * q) = ov;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- phase 2: conv2(t) from T + shortcut (composed 3x3 stride-2 conv of the raw planes, fp32) + relu -> b0 ----
+    for (int pb = wave; pb < TH * TW / 32; pb += NW) {
+      const int y = pb, x = p;
+      float16v acc, accs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accs[r] = 0.f; }
+      {
+        const int base = (y * T_W + x) * PS + h * 16;
+        auto frag = [&](int item) -> half8 {
+          const int tp = item >> 1, ks = item & 1, dy = tp / 3, dx = tp - dy * 3;
+          return *(const half8 *)(T + base + (dy * T_W + dx) * PS + ks * 32);
+        };
+        // weight fragments from the resident LDS copy (this kernel is VGPR-bound: biases + composed weights + prefetch)
+        half8 bf[3], af[3];
+        bf[0] = frag(0); af[0] = *(const half8 *)(W2 + lane * 16);
+        bf[1] = frag(1); af[1] = *(const half8 *)(W2 + 1024 + lane * 16);
+#pragma unroll
+        for (int item = 0; item < 18; ++item) {
+          if (item + 2 < 18) {
+            bf[(item + 2) % 3] = frag(item + 2);
+            af[(item + 2) % 3] = *(const half8 *)(W2 + (item + 2) * 1024 + lane * 16);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[item % 3], bf[item % 3], acc, 0, 0, 0);
+        }
+      }
+      {
+        const int o = (2 * (y + 1)) * RP + x + 1;  // this pixel's window origin in the raw patch (t-region coords y+1, x+1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 b;
+          uint32_t *bw = (uint32_t *)&b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int t0 = 8 * ks + e, t1 = 8 * ks + 4 + e;
+            const uint32_t v0 = t0 < 9 ? raw[o + tap(1 + t0 / 3, 1 + t0 % 3)] : 0u;
+            const uint32_t v1 = t1 < 9 ? raw[o + tap(1 + t1 / 3, 1 + t1 % 3)] : 0u;
+            bw[e] = h ? v1 : v0;
+          }
+          accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[ks], b, accs, 0, 0, 0);
+        }
+      }
+      half4 hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b2r[q][e] + (accs[4 * q + e] * a.acc_scale + bsr[q][e]), 0.f);
+      const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * 32 + (size_t)(tx * TW + x) * 32 + 8 * h;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
+    }
+    if (t_next < ntiles) __builtin_amdgcn_s_barrier();  // the next commit overwrites raw, the next phase 1 overwrites T
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Heads + argmax (arch:282-297, EncCu.cpp:913-921).  One workgroup per CU; fp32 throughout.
 // feat = (sum of the GAP partial sums written by the stage's last conv) / HW
@@ -1169,6 +1357,12 @@ hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) 
     configured = true;
   }
   hipLaunchKernelGGL(block32_kernel, dim3(grid_x), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st) {
+  constexpr int lds = (39 * 72 * 4 + 15) / 16 * 16 + 18 * 34 * 80 + 18 * 1024;
+  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(512), lds, st, a);  // 78 KiB: two workgroups per CU
   return hipGetLastError();
 }
 
