@@ -21,6 +21,10 @@ def per_kernel(path, counter):
         if m:
             cin, cout, st = map(int, m.groups())
             name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")
+        elif "stem_block_kernel" in k:
+            name = "stem+block_s2_2to32_h64(layer0.0)"
+        elif "block32_kernel" in k:
+            name = "block_s1_32_h64(conv1+conv2)"
         elif "stem5_kernel" in k:
             name = "stem5x5_s2_2to32_h64+sc"
         elif "heads_kernel" in k:
