@@ -19,6 +19,7 @@ ERR_NAMES = {1: "MLT_ERR_ARG", 2: "MLT_ERR_NO_DEVICE", 3: "MLT_ERR_WEIGHTS", 4: 
 SIZE_BITS = {128: 1, 64: 2, 32: 4, 16: 8}
 FLAG_EXACT_128 = 0x1   # 128x128 in exact (fp16 hi+lo, 3-pass) arithmetic instead of fast
 FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
+FLAG_DECISION_GUARD = 0x4  # host entry points re-evaluate near-tie CUs with the exact arithmetic
 EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
@@ -27,7 +28,7 @@ EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "ml
 class MltConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("weights_dir", C.c_char_p),
                 ("size_mask", C.c_uint32), ("head_index", C.c_int32 * 4), ("max_batch", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("guard_margin", C.c_float)]
 
 
 class MltKernelTime(C.Structure):
@@ -88,7 +89,7 @@ class MltCnn:
     """One context = one HIP device + one stream (one per encoder thread / EncCu instance)."""
 
     def __init__(self, device: int = 0, sizes=(128,), weights_dir: str | None = None, blobs: dict | None = None,
-                 head_index: dict | None = None, max_batch: int = 4096, flags: int = 0):
+                 head_index: dict | None = None, max_batch: int = 4096, flags: int = 0, guard_margin: float = 0.0):
         self._lib = load_library()
         cfg = MltConfig()
         cfg.struct_size = C.sizeof(MltConfig)
@@ -99,6 +100,7 @@ class MltCnn:
             cfg.head_index[i] = (head_index or {}).get(s, -1)
         cfg.max_batch = max_batch
         cfg.flags = flags
+        cfg.guard_margin = guard_margin
         self._h = C.c_void_p()
         rc = self._lib.mlt_init(C.byref(cfg), C.byref(self._h))
         if rc != MLT_OK:
@@ -141,16 +143,16 @@ class MltCnn:
                                           pred.strides[0] // 2, S, int(poc), int(qp), C.byref(split), logits.ctypes.data))
         return int(split.value), logits
 
-    def predict_batch(self, org: np.ndarray, pred: np.ndarray, poc, qp):
+    def predict_batch(self, org: np.ndarray, pred: np.ndarray, poc, qp, want_logits: bool = True):
         org = np.ascontiguousarray(org, np.int16)
         pred = np.ascontiguousarray(pred, np.int16)
         n, S, _ = org.shape
         poc = np.ascontiguousarray(poc, np.int32)
         qp = np.ascontiguousarray(qp, np.int32)
         split = np.full((n,), -1, np.int32)
-        logits = np.zeros((n, self.num_logits(S) or 1), np.float32)
+        logits = np.zeros((n, self.num_logits(S) or 1), np.float32) if want_logits else None
         self._check(self._lib.mlt_predict_batch(self._h, n, S, org.ctypes.data, pred.ctypes.data, poc.ctypes.data,
-                                                qp.ctypes.data, split.ctypes.data, logits.ctypes.data))
+                                                qp.ctypes.data, split.ctypes.data, logits.ctypes.data if want_logits else None))
         return split, logits
 
     def predict_batch_device(self, n: int, size: int, d_org: int, d_pred: int, d_poc: int, d_qp: int, d_split: int,

@@ -37,9 +37,10 @@ int size_index(int size) {
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct SizeState {
-  bool enabled = false, loaded = false, exact = false;
+  bool enabled = false, loaded = false, exact = false, guard = false;
   int size = 0, head_index = 0;
   mlt::Model model;
+  mlt::Model model_exact;  // decision guard: exact-arithmetic copy used to re-evaluate near-tie CUs
 };
 
 // mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
@@ -62,9 +63,11 @@ struct mlt_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   SizeState sz[4];
+  float guard_margin = 0.02f;
   int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
+  char *zero_page = nullptr;  // 64 KiB of zeros: padding source of the LDS-DMA patch staging
   SingleCu single[4];
   // staging for the host-pointer entry points
   char *stage = nullptr;
@@ -209,7 +212,9 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
-  const int MT = pc.mt;
+  // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
+  const int dma = pc.exact ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
+  const int MT = dma == 2 ? pc.mt_dma : pc.mt;
   const int nsplit = pc.exact ? 2 : 1;
   int tw = hout < 32 ? hout : 32;
   int th = MT / tw < hout ? MT / tw : hout;
@@ -229,6 +234,11 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   auto magic = [](int d) { return (uint32_t)((0x100000000ull + d - 1) / d); };  // d >= 2 (ph, pw >= 3)
   a.pw_magic = magic(pw); a.ph_magic = magic(ph);
   a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
+  if (dma) {  // two unpadded, swizzled patch buffers; the row pitch keeps the rules above
+    a.patch_bytes = (int)((((size_t)spw * ph * rp * pc.kc * 2) + 1023) / 1024 * 1024);
+    a.rp_magic = magic(rp);
+    a.zero = ctx->zero_page;
+  }
   const int extra_lds = 0;
   const int hw = hout * hout;
   a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
@@ -236,8 +246,10 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
-  const bool persistent = pc.gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc;
-  const int grid_x = (persistent && a.ntiles > wg_cap) ? wg_cap : a.ntiles;
+  const bool persistent = (pc.gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
+  // ring-DMA: one 16-wave or two 8-wave workgroups per CU, counted over all cout tiles
+  const int cap = dma == 2 ? wg_cap * (pc.mt_dma >= 256 ? 1 : 2) / (pc.cout / pc.ct) : wg_cap;
+  const int grid_x = (persistent && a.ntiles > cap) ? cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "conv3x3_s%d_%dto%d_h%d%s", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");
   const double px = (double)n * hw;
@@ -248,7 +260,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, a, grid_x, extra_lds, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, dma != 0, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
@@ -330,9 +342,8 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
 }
 
 // One chunk of n CUs through the whole network, everything on ctx->stream.
-int run_network(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs,
-                long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
-  mlt::Model &m = st.model;
+int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
+                long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
   const int S = st.size;
   int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
   if (rc) return rc;
@@ -436,6 +447,23 @@ int ensure_stage(mlt_ctx *ctx, size_t bytes) {
   return MLT_OK;
 }
 
+// Decision guard (MLT_FLAG_DECISION_GUARD): indices of the CUs whose decision-head top-2 margin is below the threshold.
+void guard_select(const SizeState &st, float margin, int n, const float *logits, std::vector<int> &idx) {
+  const mlt::Model &m = st.model;
+  int off = 0;
+  for (int h = 0; h < st.head_index; ++h) off += m.heads[h].classes;
+  const int k = m.heads[st.head_index].classes, nl = m.n_logits;
+  idx.clear();
+  for (int i = 0; i < n; ++i) {
+    const float *l = logits + (size_t)i * nl + off;
+    float a = -3.4e38f, b = -3.4e38f;
+    for (int c = 0; c < k; ++c) {
+      if (l[c] > a) { b = a; a = l[c]; } else if (l[c] > b) b = l[c];
+    }
+    if (!(a - b >= margin)) idx.push_back(i);  // also catches NaN
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -458,10 +486,17 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   std::string err;
   if (!mlt::build_model(blob, bytes, st.exact, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
-  if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); st.loaded = false; }
+  if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); free_model(st.model_exact); st.loaded = false; }
   st.model = std::move(m);
   int rc = upload_model(ctx, st.model);
   if (rc) return rc;
+  if (st.guard && !st.exact) {
+    mlt::Model me;
+    if (!mlt::build_model(blob, bytes, true, me, err)) { ctx->err = "weights (exact copy): " + err; return MLT_ERR_WEIGHTS; }
+    if (st.model_exact.on_device) free_model(st.model_exact);
+    st.model_exact = std::move(me);
+    if ((rc = upload_model(ctx, st.model_exact))) return rc;
+  }
   if (st.head_index < 0 || st.head_index >= st.model.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
   st.loaded = true;
   return MLT_OK;
@@ -481,8 +516,15 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   if (!ctx) return MLT_ERR_NOMEM;
   ctx->device = cfg->device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
+  if (cfg->guard_margin > 0.f) ctx->guard_margin = cfg->guard_margin;
   if (const char *e = std::getenv("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_init_error = "hipStreamCreate failed"; delete ctx; return MLT_ERR_HIP; }
+  if (hipMalloc((void **)&ctx->zero_page, 65536) != hipSuccess || hipMemset(ctx->zero_page, 0, 65536) != hipSuccess) {
+    g_init_error = "zero page allocation failed";
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MLT_ERR_NOMEM;
+  }
   ctx->own_stream = true;
   const uint32_t mask = cfg->size_mask ? cfg->size_mask : MLT_SIZE_128;  // reference gate: 128 only (EncCu.cpp:754)
   static const int sizes[4] = {128, 64, 32, 16};
@@ -493,6 +535,7 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     // precision: 128 -> fast (single fp16 pass) unless MLT_FLAG_EXACT_128; 64/32/16 -> exact (fp16 hi+lo pairs, 3 passes)
     // unless MLT_FLAG_FAST_SMALL.  See DESIGN.md "Numerics".
     st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
+    st.guard = (cfg->flags & MLT_FLAG_DECISION_GUARD) != 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];
@@ -519,7 +562,7 @@ void mlt_shutdown(mlt_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->prof)
     for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  for (int i = 0; i < 4; ++i) free_model(ctx->sz[i].model);
+  for (int i = 0; i < 4; ++i) { free_model(ctx->sz[i].model); free_model(ctx->sz[i].model_exact); }
   for (SingleCu &sg : ctx->single) {
     if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
     if (sg.graph) (void)hipGraphDestroy(sg.graph);
@@ -527,6 +570,7 @@ void mlt_shutdown(mlt_ctx *ctx) {
     if (sg.d_stage) (void)hipFree(sg.d_stage);
   }
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -566,7 +610,7 @@ int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, c
   const long cs = (long)size * size;
   for (int i0 = 0; i0 < n; i0 += ctx->chunk) {
     const int c = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-    rc = run_network(ctx, *st, c, (const int16_t *)d_org + (size_t)i0 * cs, size, cs, (const int16_t *)d_pred + (size_t)i0 * cs, size, cs,
+    rc = run_network(ctx, *st, st->model, c, (const int16_t *)d_org + (size_t)i0 * cs, size, cs, (const int16_t *)d_pred + (size_t)i0 * cs, size, cs,
                      (const int32_t *)d_poc + i0, (const int32_t *)d_qp + i0, (int32_t *)d_split_mode + i0,
                      d_logits ? (float *)d_logits + (size_t)i0 * nl : nullptr);
     if (rc) return rc;
@@ -594,16 +638,51 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
   int32_t *d_poc = (int32_t *)(ctx->stage + 2 * plane), *d_qp = (int32_t *)(ctx->stage + 2 * plane + small);
   int32_t *d_split = (int32_t *)(ctx->stage + 2 * plane + 2 * small);
   float *d_lg = (float *)(ctx->stage + 2 * plane + 3 * small);
+  const bool guard = st->guard && !st->exact;
+  std::vector<float> own_lg;  // the guard selects on host logits; keep a private copy if the caller wants none
+  float *const user_logits = logits;
+  if (guard && !logits) { own_lg.resize((size_t)n * nl); logits = own_lg.data(); }
   for (int i0 = 0; i0 < n; i0 += cap) {
     const int c = n - i0 < cap ? n - i0 : cap;
     HIP_TRY(ctx, hipMemcpyAsync(d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = run_network(ctx, *st, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
+    if ((rc = run_network(ctx, *st, st->model, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(split_mode + i0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits) HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)i0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (guard) {  // re-evaluate near-tie CUs with the exact arithmetic
+    const float *lg = logits;
+    std::vector<int> idx;
+    guard_select(*st, ctx->guard_margin, n, lg, idx);
+    if (!idx.empty()) {
+      const int k = (int)idx.size();
+      std::vector<int16_t> go((size_t)k * cs), gp((size_t)k * cs);
+      std::vector<int32_t> gpoc(k), gqp(k), gs(k);
+      std::vector<float> gl((size_t)k * nl);
+      for (int j = 0; j < k; ++j) {
+        std::memcpy(go.data() + (size_t)j * cs, org + (size_t)idx[j] * cs, cs * 2);
+        std::memcpy(gp.data() + (size_t)j * cs, pred + (size_t)idx[j] * cs, cs * 2);
+        gpoc[j] = poc[idx[j]]; gqp[j] = qp[idx[j]];
+      }
+      for (int j0 = 0; j0 < k; j0 += cap) {
+        const int c = k - j0 < cap ? k - j0 : cap;
+        HIP_TRY(ctx, hipMemcpyAsync(d_org, go.data() + (size_t)j0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pred, gp.data() + (size_t)j0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_poc, gpoc.data() + j0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_qp, gqp.data() + j0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = run_network(ctx, *st, st->model_exact, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(gs.data() + j0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(gl.data() + (size_t)j0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      }
+      for (int j = 0; j < k; ++j) {
+        split_mode[idx[j]] = gs[j];
+        if (user_logits) std::memcpy(user_logits + (size_t)idx[j] * nl, gl.data() + (size_t)j * nl, (size_t)nl * 4);
+      }
+    }
   }
   return MLT_OK;
 }
@@ -643,10 +722,10 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
     }
     if (!sg.exec) {
       // first call: run eagerly once (allocates the workspace, configures every kernel), then capture the same chain
-      if ((rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+      if ((rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
+        rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
         hipGraph_t g = nullptr;
         const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
         if (rc == MLT_OK && ce == hipSuccess && g && hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
@@ -663,9 +742,18 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
       replayed = true;
     }
   }
-  if (!replayed && (rc = run_network(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+  if (!replayed && (rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (st->guard && !st->exact) {  // near-tie on the decision head: re-evaluate this CU with the exact arithmetic
+    std::vector<int> idx;
+    guard_select(*st, ctx->guard_margin, 1, (const float *)(h_sc + 4), idx);
+    if (!idx.empty()) {
+      if ((rc = run_network(ctx, *st, st->model_exact, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
   *split_mode = h_sc[2];
   if (logits_opt) std::memcpy(logits_opt, h_sc + 4, (size_t)nl * 4);
   return MLT_OK;

@@ -12,12 +12,13 @@ struct ConvArgs {
   const void *w;      // packed fp16 weights (mlt_model.cpp: pack_conv)
   const float *bias;  // folded BN bias per output channel
   const void *res;    // optional residual, same shape as y (NULL: none)
+  const void *zero;   // >= 64 KiB of zeros (DMA staging fetches padding from here)
   int n;
   int ntiles;                  // logical tiles (grid.x may be smaller: workgroups are persistent over tiles)
   int hin_l, hout_l;           // log2 of input / output height (= width)
   int tw_l, th_l, spw_l;       // log2 of tile width, tile height, samples per workgroup
   int ph, pw, rp, half;        // patch rows, cols, row pitch (pixels), parity-split half width
-  uint32_t pw_magic, ph_magic; // ceil(2^32 / d), d >= 2
+  uint32_t pw_magic, ph_magic, rp_magic; // ceil(2^32 / d), d >= 2
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
   float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
@@ -31,7 +32,7 @@ struct ConvArgs {
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };
 
-struct ConvCfg { int kc, ct, mt, gt; };  // cin chunk, couts / pixels per workgroup, taps per weight step
+struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma; };  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
 
 struct Stem5Args {
   const int16_t *org, *pred;   // Pel planes
@@ -77,7 +78,7 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
 hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);

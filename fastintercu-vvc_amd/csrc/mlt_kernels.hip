@@ -17,11 +17,37 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "mlt_kernels.h"
 
-// build-time tuning knob (scripts/sweep_cfg.py)
+// build-time tuning knobs (scripts/sweep_cfg.py)
+#ifndef CFG_ASM_PIPE  // 1: fragment ds_reads issued from inline asm, 2 items ahead, with counted lgkmcnt waits (fast arithmetic)
+#define CFG_ASM_PIPE 1
+#endif
 #ifndef CFG_BIAS_EARLY  // 1: bias loads before the MFMA phase (latency hidden, +16..32 VGPRs); 0: at the epilogue
 #define CFG_BIAS_EARLY 1
+#endif
+
+// -DMLT_PHASE_TIMING: wave 0 of every conv_mfma_kernel workgroup accumulates s_memtime deltas per phase into g_phase
+// (debug builds only, scripts/phase_timing.py; perturbs the pipelining slightly)
+#ifdef MLT_PHASE_TIMING
+__device__ unsigned long long g_phase[16][8];
+extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long z[16][8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#define PH_DECL unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter()
+#define PH_MARK(i) do { unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_FLUSH(id) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase[id][i_], ph_acc[i_]); } } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH(id)
 #endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -37,6 +63,30 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void glds16(const void *gsrc_lane, void *lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc_lane), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>), so that the index can
+// feed asm immediates and if constexpr
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+// Fragment reads from inline asm.  While an LDS-DMA (global_load_lds) is pending the compiler makes every LDS wait an
+// s_waitcnt lgkmcnt(0) and sinks the reads of the next item below the MFMAs of the current one, i.e. read -> full
+// drain -> MFMA with the LDS latency exposed every item (seen in the ISA of every weight-ring kernel).  Reads issued
+// here are invisible to that logic: they stay where they are written, and lds_wait<N>() + lds_touch() state exactly
+// how many younger reads may still be in flight when a fragment is consumed (LDS operations of a wave return in order).
+template <int OFF> __device__ __forceinline__ void lds_read128(half8 &dst, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_touch(half8 &v) { asm volatile("" : "+v"(v)); }  // orders the consumer after lds_wait
 
 // n / d for d >= 2 with magic = ceil(2^32 / d); exact while n * d < 2^32 (patch indices are < 2^16)
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
@@ -79,430 +129,17 @@ __device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Generic conv (3x3 pad 1 or 1x1 pad 0, stride 1 or 2), NHWC fp16 -> NHWC fp16, fp32 accumulate.
-// One workgroup: MT = 32*WPB*WAVES_P output pixels (SPW samples x TH x TW) x CT = 32*WCB*WAVES_C
-// output channels.  Per 64-or-32-channel input chunk the (haloed) input patch is staged ONCE in LDS
-// and reused by all taps; weights stream through a double-buffered LDS ring by LDS-DMA, GT taps per step.
-//   SC   : the block's 1x1 stride-2 projection shortcut (arch:44-50) rides along as weight "tap 9" on the
-//          same patch and leaves through a second accumulator / output (y_sc).
-//   gap  : fp32 per-channel partial sums of the activated output (global average pooling, arch:282).
+// Shared epilogue of the conv kernels: + bias (+ residual) (ReLU) -> fp16 NHWC (16 B per lane and quad pair) and/or
+// fp32 GAP partial sums; SC: second output (projection shortcut, no ReLU).  The caller has loaded the biases (bq / bsq)
+// and, when a.res is set, the residual (resv / resl) into registers.
 // ---------------------------------------------------------------------------------------------
-//   NSPLIT = 2 ("exact" mode): every activation and weight is an fp16 (hi, lo) pair with hi + lo == the fp32
-//          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
-//          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
-//          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW>
-// MINW = minimum waves per SIMD (second __launch_bounds__ argument, caps the VGPR allocation); 1 = unconstrained
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel(const ConvArgs a) {
-  static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
-  constexpr int NCHUNK = CIN / KC;
-  constexpr int KS = KC / 16;
-  constexpr int SLOTS = KC / 8;          // 16-byte slots per pixel
-  constexpr int PS = KC * 2 + 16;        // LDS pixel stride (bytes); PS/16 odd -> conflict-free rows
-  constexpr int CBT = WCB * WAVES_C;     // 32-channel blocks per workgroup tile
-  constexpr int CT = 32 * CBT;
-  constexpr int NW = WAVES_C * WAVES_P;
-  constexpr int NT = 64 * NW;
-  constexpr int TT = TAPS + (SC ? 1 : 0);  // weight steps per chunk (taps + shortcut)
-  constexpr int NG = TT / GT;
-  constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step (per split plane)
-  constexpr int NBUF = NG > 1 ? RB : 1;         // weight ring depth; steps are prefetched NBUF-1 ahead
-  constexpr int PFD = NBUF > 1 ? NBUF - 1 : 0;  // prefetch distance (steps)
-  constexpr int NPIECE = WCHUNK / 1024;                       // 1 KiB LDS-DMA pieces per step and plane
-  constexpr int PPW = NSPLIT * ((NPIECE + NW - 1) / NW);      // LDS-DMA instructions EVERY wave issues per step
-  constexpr int PAD = TAPS == 9 ? 1 : 0;
-  constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
-  static_assert(TT % GT == 0, "tap grouping");
-  static_assert(COUT % CT == 0, "cout tiling");
-  static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
-  static_assert(RB >= 1 && RB <= 4, "ring depth");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *patch = smem;                                  // [NSPLIT][patch_bytes]
-  char *wring = smem + NSPLIT * a.patch_bytes;         // [NBUF][NSPLIT][WCHUNK]
-  const size_t w_lo = a.w_lo_off;                      // byte offset of the lo weight plane (NSPLIT == 2)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave % WAVES_C, wp = wave / WAVES_C;
-  const int p = lane & 31, h = lane >> 5;
-
-  // ---- geometry (all powers of two) ----
-  const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l;
-  const int TW = 1 << tw_l, TH = 1 << th_l;
-  const int hout_l = a.hout_l, hin_l = a.hin_l;
-  const int Hin = 1 << hin_l;
-  const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;  // tiles per row / column of one sample
-  const int PH = a.ph, PW = a.pw, RP = a.rp, HALF = a.half;
-  const int m_valid = 1 << (tw_l + th_l + spw_l);
-  const int ctile = blockIdx.y;
-  const int ntiles = a.ntiles;
-
-  // Workgroups are PERSISTENT over tiles (t = blockIdx.x, += gridDim.x).  XCD-aware order: workgroups are dealt
-  // round-robin over the 8 XCDs (private L2 each); logical tile t maps to a physical tile so that every XCD owns a
-  // CONTIGUOUS run of tiles (neighbouring tiles share halo rows -> same L2).  Bijective for any ntiles (T1).
-  auto tile_decode = [&](int t, int &tx, int &ty, int &n0) {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
-    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-    tx = mt & ((1 << txs_l) - 1);
-    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
-    n0 = (mt >> (txs_l + tys_l)) << spw_l;
-  };
-
-  // ---- patch loader, split into ISSUE (global -> registers, asynchronous) and COMMIT (registers -> LDS) so that
-  // the loads of the NEXT stage (next channel chunk, or the next tile's first chunk) fly while THIS stage computes ----
-  // UN (template): patch items per lane held in registers across a stage; larger patches take the synchronous tail
-  constexpr int PSTEP = NT / SLOTS;                       // pixels advanced per item step; a lane's 16-byte slot is fixed
-  const int slot = tid & (SLOTS - 1);
-  const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
-  const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
-  half8 pv[UN], pvl[NSPLIT == 2 ? UN : 1];
-  int pdst[UN];  // LDS byte offset; bit 30 set: zero-fill (outside the picture / batch); -1: no item
-  // Branch-free: every load is issued (from a clamped, always-valid address, DISTINCT per lane and workgroup -- never one
-  // shared hot line) before any result is used; a conditional load would be waited for inside its branch.
-  auto load_item = [&](int it, int rr, int px, int n0, int iy0, int ix0, int chunk, half8 &v, half8 &vl, int &dst, bool &live) {
-    const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
-    const int iy = iy0 + py, ix = ix0 + px;
-    const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
-    dst = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
-    live = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
-    const size_t safe_off = ((((size_t)n0 << hin_l) << hin_l) * CIN) + (size_t)((tid * 8) & ((CIN << (2 * hin_l)) - 1) & ~7);
-    const size_t off = live ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : safe_off;
-    v = *(const half8 *)((const _Float16 *)a.x + off);
-    if constexpr (NSPLIT == 2) vl = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
-  };
-  auto issue_patch = [&](int t, int chunk) {
-    int tx, ty, n0;
-    tile_decode(t, tx, ty, n0);
-    const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
-    int rr = udiv_magic(tid / SLOTS, a.pw_magic), px = tid / SLOTS - rr * PW;  // rr = row counter over (sample, py)
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      half8 dummy;
-      bool live;
-      load_item(tid + u * NT, rr, px, n0, iy0, ix0, chunk, pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : dummy, pdst[u], live);
-      if (!live && pdst[u] >= 0) pdst[u] |= 1 << 30;
-      px += step_x; rr += step_r;
-      if (px >= PW) { px -= PW; ++rr; }
-    }
-  };
-  auto put_item = [&](half8 v, half8 vl, int dst, bool live) {
-    if (!live) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
-    }
-    if (dst >= 0) {
-      *(half8 *)(patch + dst) = v;
-      if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst) = vl;
-    }
-  };
-  auto commit_patch = [&](int t, int chunk) {
-#pragma unroll
-    for (int u = 0; u < UN; ++u) put_item(pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : pv[u], pdst[u] < 0 ? -1 : (pdst[u] & ~(1 << 30)), !(pdst[u] & (1 << 30)));
-    if (patch_items > UN * NT) {  // oversized patch (tiny maps, many samples per tile): the rest synchronously
-      int tx, ty, n0;
-      tile_decode(t, tx, ty, n0);
-      const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
-      for (int it = tid + UN * NT; it < patch_items; it += NT) {
-        const int pix = it / SLOTS, rr = udiv_magic(pix, a.pw_magic), px = pix - rr * PW;
-        half8 v, vl;
-        int dst;
-        bool live;
-        load_item(it, rr, px, n0, iy0, ix0, chunk, v, vl, dst, live);
-        put_item(v, vl, dst, live);
-      }
-    }
-  };
-
-  // ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32 for the upper half,
-  // MI355X_MICROARCH.md LDS table).  With PS/16 odd a group is conflict-free iff its 16 patch-pixel indices are
-  // distinct mod 16, so lanes are RANKED such that each group owns 16 consecutive logical pixels: one 16-pixel row
-  // segment (TW >= 16) or, for 8-wide maps, two 8-pixel rows 4/STRIDE apart (their patch rows are then
-  // 4 * RP = 8 (mod 16) pixels apart because the host keeps RP = 2 (mod 4)).  Only used when a 32-pixel block lies
-  // inside one sample (H*W >= 32); smaller maps keep the natural order the GAP butterfly relies on.
-  const bool rank_lanes = (tw_l + th_l) >= 5;
-  int pr = p;
-  if (rank_lanes) pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
-  const bool pair_rows = rank_lanes && tw_l == 3 && th_l >= 3;
-  // tile-independent part of the lane -> pixel map, packed: x[0:5) y[5:10) slot[10:18) sample[18:30) ok[30]
-  int base[WPB], lmap[WPB];
-#pragma unroll
-  for (int j = 0; j < WPB; ++j) {
-    const int m = (wp * WPB + j) * 32 + pr;
-    const bool ok = m < m_valid;
-    const int mm = ok ? m : 0;
-    const int x = mm & (TW - 1);
-    int q = mm >> tw_l;  // row counter over (sample, y)
-    if (pair_rows) {
-      const int k = q & 7;
-      const int kp = STRIDE == 1 ? (((k & 1) << 2) | (k >> 1)) : ((k & 4) | ((k & 1) << 1) | ((k >> 1) & 1));
-      q = (q & ~7) | kp;
-    }
-    const int y = q & (TH - 1), sm = q >> th_l;
-    base[j] = ((sm * PH + y * STRIDE) * RP + x) * PS + h * 16;  // LDS byte offset of (pixel, tap (0,0), slot h)
-    lmap[j] = x | (y << 5) | (((mm & ((1 << (tw_l + th_l)) - 1)) >> 5) << 10) | (sm << 18) | ((ok ? 1 : 0) << 30);
-  }
-
-  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
-  auto issue_step = [&](int chunk, int g, int buf) {
-    const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
-    char *dst = wring + buf * NSPLIT * WCHUNK;
-    // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
-    // its own re-copies the last piece (same bytes to the same place: benign)
-#pragma unroll
-    for (int sp = 0; sp < NSPLIT; ++sp)
-#pragma unroll
-      for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
-        int pi = wave + k * NW;
-        pi = pi < NPIECE ? pi : NPIECE - 1;
-        glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
-      }
-  };
-  // weights that fit one step and one chunk stay resident in LDS for the life of the (persistent) workgroup
-  constexpr bool W_RESIDENT = NG == 1 && NCHUNK == 1;
-  // Cross-stage prefetch keeps ~UN*4 + 16 more VGPRs live through the MFMA loop.  It pays where the loop is short and
-  // there is no weight ring competing for registers / the vmcnt queue (the 32-channel layers, measured 0.70 -> 0.50 ms);
-  // the ring kernels lose more occupancy than they gain and load each stage's patch right before committing it.
-  constexpr bool PREFETCH = W_RESIDENT;
-  // Persistence (several tiles per workgroup) only where it pays: a real tile loop makes the compiler keep far more state
-  // live (64@32: 79 -> 168 VGPRs, 2 -> 1 workgroups per CU).  Ring kernels run exactly one tile per workgroup (grid.x = ntiles).
-  constexpr bool PERSIST = W_RESIDENT;
-  if constexpr (W_RESIDENT) issue_step(0, 0, 0);
-
-  // residual prefetch registers (16 B per lane and quad pair, see pair16)
-  constexpr int NRES = WCB * WPB * 2 * NSPLIT;  // residual loads per lane
-  uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
-
-  int t = blockIdx.x;
-  if (PREFETCH && t < ntiles) issue_patch(t, 0);
-
-  int lane16 = lane * 16;
-  for (; t < ntiles; t = PERSIST ? t + (int)gridDim.x : ntiles) {
-    // The tile loop must not become a reason to keep every tile-invariant address term in registers: without this the
-    // compiler hoists them all out of the loop (64@32: 79 -> 168 VGPRs, one workgroup per CU instead of two).  Passing the
-    // few base values through an empty asm makes everything derived from them loop-variant again.
-#pragma unroll
-    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(base[j]));
-    asm volatile("" : "+v"(lane16));
-    int RPt = RP, HALFt = HALF;
-    asm volatile("" : "+s"(RPt), "+s"(HALFt));
-    int tx, ty, n0;
-    tile_decode(t, tx, ty, n0);
-    int opix[WPB];  // output pixel index (flattened n,y,x) or -1
-    int gidx[WPB];  // gap partial-sum row (sample * nslots + slot) or -1
-#pragma unroll
-    for (int j = 0; j < WPB; ++j) {
-      const int lxj = lmap[j] & 31, lyj = (lmap[j] >> 5) & 31, lsl = (lmap[j] >> 10) & 255, lsj = (lmap[j] >> 18) & 4095;
-      const bool ok = (lmap[j] >> 30) && (n0 + lsj) < a.n;
-      const int oy = (ty << th_l) + lyj, ox = (tx << tw_l) + lxj;
-      opix[j] = ok ? ((((n0 + lsj) << hout_l) + oy) << hout_l) + ox : -1;
-      const int tile_in_sample = (ty << txs_l) + tx;
-      gidx[j] = ok ? (n0 + lsj) * a.gap_slots + ((tile_in_sample << (tw_l + th_l)) >> 5) + lsl : -1;
-    }
-    const int t_next = PERSIST ? t + (int)gridDim.x : ntiles;
-    // folded BN biases of this lane's output channels: issued here so the loads fly under the staging / MFMA phase
-    // (a load placed in the epilogue is waited for on the spot)
-    float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
-    auto load_biases = [&]() {
-#pragma unroll
-      for (int i = 0; i < WCB; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-          if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-        }
-    };
-    // early (latency hidden under the MFMA phase, +16..32 live VGPRs) where registers are not the occupancy limiter;
-    // the stride-1 ring kernels load them at the epilogue (measured: 128@16 0.41 vs 0.48 ms)
-    constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || SC);
-    if constexpr (BIAS_EARLY) load_biases();
-
-    float16v acc[WCB][WPB];
-    float16v acc_sc[SCW][SPB];
-#pragma unroll
-    for (int i = 0; i < WCB; ++i)
-#pragma unroll
-      for (int j = 0; j < WPB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < SCW; ++i)
-#pragma unroll
-      for (int j = 0; j < SPB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
-
-    // what flies during the LAST weight steps of a chunk: the next stage's patch and, before the epilogue, the residual
-    auto prefetch_next = [&](int chunk) {
-      if constexpr (!PREFETCH) return;
-      if (chunk + 1 < NCHUNK) issue_patch(t, chunk + 1);
-      else if (t_next < ntiles) issue_patch(t_next, 0);
-      else {  // nothing follows: keep the number of outstanding loads identical (the counted waits depend on it)
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          pv[u] = *(const half8 *)((const _Float16 *)a.x + (size_t)(tid & 255) * 8);
-          if constexpr (NSPLIT == 2) pvl[u] = pv[u];
-          pdst[u] = -1;
-        }
-      }
-      if (W_RESIDENT && chunk + 1 == NCHUNK && a.res) {  // residual reads (uniform branch): clamped address when the pixel is invalid
-#pragma unroll
-        for (int i = 0; i < WCB; ++i)
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
-              if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
-            }
-          }
-      }
-    };
-    // loads in flight behind the ring's last counted wait of a chunk (prefetch_next): patch items (+ residual)
-    const int PF_PATCH = UN * NSPLIT;
-
-    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-      if constexpr (!PREFETCH) issue_patch(t, chunk);
-      commit_patch(t, chunk);  // registers -> LDS (the compiler waits for exactly these loads here)
-      if constexpr (!W_RESIDENT) {
-        issue_step(chunk, 0, 0);
-#pragma unroll
-        for (int d = 1; d < PFD; ++d)
-          if (d < NG) issue_step(chunk, d, d);
-      }
-      if constexpr (NBUF > 1) {
-        // step 0 must have landed; the PFD-1 younger steps may stay in flight.  LDS-DMA data is ordered for another
-        // wave's ds_read only by the ISSUING wave's vmcnt followed by a barrier; the patch ds_writes need lgkmcnt(0).
-        constexpr int INFL0 = (PFD - 1 < NG - 1 ? PFD - 1 : NG - 1) * PPW;
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL0) : "memory");
-      } else if constexpr (W_RESIDENT) {
-        // The resident weights' LDS-DMA is older than the first patch loads, so the wait commit_patch needed for those
-        // already covers it.  Only the patch ds_writes must be visible: lgkmcnt(0) + raw barrier -- a __syncthreads()
-        // would add vmcnt(0) and expose the previous tile's epilogue STORES (vmcnt counts stores on CDNA4).
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        prefetch_next(chunk);  // single weight step: the whole MFMA phase + epilogue hide these loads
-      } else {
-        __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
-        prefetch_next(chunk);
-      }
-
-      int cur_buf = 0;
-#pragma unroll 1
-      for (int g = 0; g < NG; ++g) {
-        char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
-        if constexpr (NBUF > 1) {
-          // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
-          if (g + PFD < NG) {
-            int nb = cur_buf + PFD;
-            if (nb >= NBUF) nb -= NBUF;
-            issue_step(chunk, g + PFD, nb);
-          }
-          // after the LAST weight step of this chunk has been issued: start the next stage's loads (they are younger than
-          // every ring operation still needed, so the counted waits below simply add them)
-          if (g + PFD == NG - 1 || (NG <= PFD && g == 0)) prefetch_next(chunk);
-        }
-        // Fragment reads run ONE (tap, k-step) ahead of the MFMAs that consume them (register double buffer), so the
-        // ds_read latency of item i+1 hides under the MFMAs of item i instead of serialising read -> wait -> MFMA.
-        auto tap_off = [&](int tt) -> int {
-          const int tp = g * GT + tt;
-          if (TAPS != 9) return 0;
-          const int te = (SC && tp == TAPS) ? 4 : tp;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
-          const int dy = te / 3, dx = te - dy * 3;
-          return STRIDE == 2 ? (dy * RPt + (dx & 1) * HALFt + (dx >> 1)) * PS : (dy * RPt + dx) * PS;
-        };
-        half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
-        auto load_frags = [&](int item, int sl) {
-          const int tt = item / KS, ks = item - tt * KS;
-          const int toff = tap_off(tt);
-#pragma unroll
-          for (int i = 0; i < WCB; ++i) {
-            af[sl][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
-            if constexpr (NSPLIT == 2) afl[sl][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
-          }
-#pragma unroll
-          for (int j = 0; j < WPB; ++j) {
-            bf[sl][j] = *(const half8 *)(patch + base[j] + toff + ks * 32);
-            if constexpr (NSPLIT == 2) bfl[sl][j] = *(const half8 *)(patch + a.patch_bytes + base[j] + toff + ks * 32);
-          }
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int item = 0; item < GT * KS; ++item) {
-          const int cur = item & 1;
-          if (item + 1 < GT * KS) load_frags(item + 1, cur ^ 1);
-          const bool is_sc = SC && (g * GT + item / KS) == TAPS;
-          if (is_sc) {
-            if constexpr (SC) {
-#pragma unroll
-              for (int i = 0; i < WCB; ++i)
-#pragma unroll
-                for (int j = 0; j < WPB; ++j) {
-                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
-                  if constexpr (NSPLIT == 2) {
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
-                  }
-                }
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < WCB; ++i)
-#pragma unroll
-              for (int j = 0; j < WPB; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                if constexpr (NSPLIT == 2) {
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                }
-              }
-          }
-        }
-        if constexpr (NBUF > 1) {
-          if (g + 1 < NG) {
-            // step g+1 must have landed; steps g+2 .. min(g+PFD, NG-1) may stay in flight, and so may the next stage's
-            // loads once they have been issued (they are younger): counted vmcnt + raw barrier (__syncthreads() would
-            // drain the whole queue with vmcnt(0))
-            const int last = g + PFD < NG - 1 ? g + PFD : NG - 1;
-            const int infl = last - (g + 1);
-            const bool pf_out = PREFETCH && g + PFD >= NG - 1;  // prefetch_next already issued
-            const bool with_res = false;  // ring kernels read the residual in the epilogue (register budget)
-            if (!pf_out) {
-              if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
-              else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
-              else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            } else if (with_res) {  // infl == 0 here: every ring step has been issued before the prefetch
-              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT + NRES) : "memory");
-            } else {
-              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT) : "memory");
-            }
-            if (++cur_buf == NBUF) cur_buf = 0;
-          }
-        }
-      }
-      // everyone is done reading this stage's patch / weights before the next commit overwrites them
-      if (chunk + 1 < NCHUNK) __builtin_amdgcn_s_barrier();
-    }
-    (void)PF_PATCH;
-  // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
+template <int COUT, int CT, int WCB, int WPB, bool SC, int NSPLIT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int wc, int h, int p, const int (&opix)[WPB], const int (&gidx)[WPB],
+                                              float16v (&acc)[WCB][WPB], float16v (&acc_sc)[SC ? WCB : 1][SC ? WPB : 1],
+                                              const float4v (&bq)[WCB][4], const float4v (&bsq)[SC ? WCB : 1][4],
+                                              const uint4v (&resv)[WCB][WPB][2],
+                                              const uint4v (&resl)[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2]) {
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
-  if constexpr (!BIAS_EARLY) load_biases();
-  if constexpr (!W_RESIDENT) {
-    if (a.res) {  // all residual reads together (16 B per lane and quad pair), clamped address when the pixel is invalid
-#pragma unroll
-      for (int i = 0; i < WCB; ++i)
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
-            if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
-          }
-        }
-    }
-  }
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
     const int cbase = ctile * CT + (wc * WCB + i) * 32 + 4 * h;
@@ -627,9 +264,923 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic conv (3x3 pad 1 or 1x1 pad 0, stride 1 or 2), NHWC fp16 -> NHWC fp16, fp32 accumulate.
+// One workgroup: MT = 32*WPB*WAVES_P output pixels (SPW samples x TH x TW) x CT = 32*WCB*WAVES_C
+// output channels.  Per 64-or-32-channel input chunk the (haloed) input patch is staged ONCE in LDS
+// and reused by all taps; weights stream through a double-buffered LDS ring by LDS-DMA, GT taps per step.
+//   SC   : the block's 1x1 stride-2 projection shortcut (arch:44-50) rides along as weight "tap 9" on the
+//          same patch and leaves through a second accumulator / output (y_sc).
+//   gap  : fp32 per-channel partial sums of the activated output (global average pooling, arch:282).
+// ---------------------------------------------------------------------------------------------
+//   NSPLIT = 2 ("exact" mode): every activation and weight is an fp16 (hi, lo) pair with hi + lo == the fp32
+//          value to ~2^-22; products are accumulated as Wh*Xh + Wh*Xl + Wl*Xh in fp32 (3 MFMAs), which
+//          restores ~fp32 accuracy on the fp16 matrix cores.  Planes: x / y / res / y_sc hold hi at the base
+//          pointer and lo at base + a.*_lo_off bytes; the LDS patch and the weight ring are doubled.
+//   DMA    (weights-resident stride-1 kernels, fast arithmetic): the patch is not staged through registers but written
+//          straight into LDS by LDS-DMA (global_load_lds), double-buffered: while the MFMAs of tile i read buffer A
+//          the DMA of tile i+1 fills buffer B, so a workgroup has a whole tile time of patch traffic in flight and
+//          no commit phase, and the only barrier per tile is the buffer swap.  The DMA writes 64 x 16 contiguous
+//          bytes per wave-instruction, so pixels cannot be padded apart; instead the 16-byte channel slots of a
+//          pixel are XOR-swizzled with the pixel index (each lane picks the GLOBAL slot it fetches) which makes the
+//          fragment ds_read_b128 conflict-free for 16 consecutive patch pixels, as the padding does in the other modes.
+//          Picture-border / batch-tail items are fetched from a zero page (a.zero).
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA>
+// MINW = minimum waves per SIMD (second __launch_bounds__ argument, caps the VGPR allocation); 1 = unconstrained
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel(const ConvArgs a) {
+  static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
+  constexpr int NCHUNK = CIN / KC;
+  constexpr int KS = KC / 16;
+  constexpr int SLOTS = KC / 8;          // 16-byte slots per pixel
+  constexpr int PS = KC * 2 + 16;        // LDS pixel stride (bytes); PS/16 odd -> conflict-free rows
+  constexpr int CBT = WCB * WAVES_C;     // 32-channel blocks per workgroup tile
+  constexpr int CT = 32 * CBT;
+  constexpr int NW = WAVES_C * WAVES_P;
+  constexpr int NT = 64 * NW;
+  constexpr int TT = TAPS + (SC ? 1 : 0);  // weight steps per chunk (taps + shortcut)
+  constexpr int NG = TT / GT;
+  constexpr int WCHUNK = GT * KS * CBT * 1024;  // bytes of one weight step (per split plane)
+  constexpr int NBUF = NG > 1 ? RB : 1;         // weight ring depth; steps are prefetched NBUF-1 ahead
+  constexpr int PFD = NBUF > 1 ? NBUF - 1 : 0;  // prefetch distance (steps)
+  constexpr int NPIECE = WCHUNK / 1024;                       // 1 KiB LDS-DMA pieces per step and plane
+  constexpr int PPW = NSPLIT * ((NPIECE + NW - 1) / NW);      // LDS-DMA instructions EVERY wave issues per step
+  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
+  static_assert(TT % GT == 0, "tap grouping");
+  static_assert(COUT % CT == 0, "cout tiling");
+  static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
+  static_assert(RB >= 1 && RB <= 4, "ring depth");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const size_t w_lo = a.w_lo_off;                      // byte offset of the lo weight plane (NSPLIT == 2)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+  char *patch = smem;                                                  // [NSPLIT][patch_bytes]; DMA: two buffers of patch_bytes
+  char *wring = smem + (DMA ? 2 : NSPLIT) * a.patch_bytes;             // [NBUF][NSPLIT][WCHUNK]
+  constexpr bool ASM_PIPE = CFG_ASM_PIPE && NSPLIT == 1;                // see lds_read128
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);            // LDS byte address of the dynamic segment
+  constexpr int PIXROW_L = KC == 64 ? 1 : 2;                           // DMA swizzle: log2(pixels per 256-byte LDS bank row)
+  const int p = lane & 31, h = lane >> 5;
+
+  // ---- geometry (all powers of two) ----
+  const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l;
+  const int TW = 1 << tw_l, TH = 1 << th_l;
+  const int hout_l = a.hout_l, hin_l = a.hin_l;
+  const int Hin = 1 << hin_l;
+  const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;  // tiles per row / column of one sample
+  const int PH = a.ph, PW = a.pw, RP = a.rp, HALF = a.half;
+  const int m_valid = 1 << (tw_l + th_l + spw_l);
+  const int ctile = blockIdx.y;
+  const int ntiles = a.ntiles;
+
+  // Workgroups are PERSISTENT over tiles (t = blockIdx.x, += gridDim.x).  XCD-aware order: workgroups are dealt
+  // round-robin over the 8 XCDs (private L2 each); logical tile t maps to a physical tile so that every XCD owns a
+  // CONTIGUOUS run of tiles (neighbouring tiles share halo rows -> same L2).  Bijective for any ntiles (T1).
+  auto tile_decode = [&](int t, int &tx, int &ty, int &n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    tx = mt & ((1 << txs_l) - 1);
+    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
+    n0 = (mt >> (txs_l + tys_l)) << spw_l;
+  };
+
+  // ---- patch loader, split into ISSUE (global -> registers, asynchronous) and COMMIT (registers -> LDS) so that
+  // the loads of the NEXT stage (next channel chunk, or the next tile's first chunk) fly while THIS stage computes ----
+  // UN (template): patch items per lane held in registers across a stage; larger patches take the synchronous tail
+  constexpr int PSTEP = NT / SLOTS;                       // pixels advanced per item step; a lane's 16-byte slot is fixed
+  const int slot = tid & (SLOTS - 1);
+  const int patch_items = (1 << spw_l) * PH * PW * SLOTS;
+  const int step_r = udiv_magic(PSTEP, a.pw_magic), step_x = PSTEP - step_r * PW;
+  half8 pv[UN], pvl[NSPLIT == 2 ? UN : 1];
+  int pdst[UN];  // LDS byte offset; bit 30 set: zero-fill (outside the picture / batch); -1: no item
+  // Branch-free: every load is issued (from a clamped, always-valid address, DISTINCT per lane and workgroup -- never one
+  // shared hot line) before any result is used; a conditional load would be waited for inside its branch.
+  auto load_item = [&](int it, int rr, int px, int n0, int iy0, int ix0, int chunk, half8 &v, half8 &vl, int &dst, bool &live) {
+    const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const int col = STRIDE == 2 ? ((px & 1) * HALF + (px >> 1)) : px;
+    dst = it < patch_items ? (rr * RP + col) * PS + slot * 16 : -1;
+    live = it < patch_items && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+    const size_t safe_off = ((((size_t)(n0 < a.n ? n0 : 0) << hin_l) << hin_l) * CIN) + (size_t)((tid * 8) & ((CIN << (2 * hin_l)) - 1) & ~7);
+    const size_t off = live ? (((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + slot * 8 : safe_off;
+    v = *(const half8 *)((const _Float16 *)a.x + off);
+    if constexpr (NSPLIT == 2) vl = *(const half8 *)((const char *)((const _Float16 *)a.x + off) + a.x_lo_off);
+  };
+  auto issue_patch = [&](int t, int chunk) {
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
+    int rr = udiv_magic(tid / SLOTS, a.pw_magic), px = tid / SLOTS - rr * PW;  // rr = row counter over (sample, py)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      half8 dummy;
+      bool live;
+      load_item(tid + u * NT, rr, px, n0, iy0, ix0, chunk, pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : dummy, pdst[u], live);
+      if (!live && pdst[u] >= 0) pdst[u] |= 1 << 30;
+      px += step_x; rr += step_r;
+      if (px >= PW) { px -= PW; ++rr; }
+    }
+  };
+  auto put_item = [&](half8 v, half8 vl, int dst, bool live) {
+    if (!live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+    }
+    if (dst >= 0) {
+      *(half8 *)(patch + dst) = v;
+      if constexpr (NSPLIT == 2) *(half8 *)(patch + a.patch_bytes + dst) = vl;
+    }
+  };
+  auto commit_patch = [&](int t, int chunk) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) put_item(pv[u], NSPLIT == 2 ? pvl[NSPLIT == 2 ? u : 0] : pv[u], pdst[u] < 0 ? -1 : (pdst[u] & ~(1 << 30)), !(pdst[u] & (1 << 30)));
+    if (patch_items > UN * NT) {  // oversized patch (tiny maps, many samples per tile): the rest synchronously
+      int tx, ty, n0;
+      tile_decode(t, tx, ty, n0);
+      const int iy0 = ((ty << th_l) * STRIDE) - PAD, ix0 = ((tx << tw_l) * STRIDE) - PAD;
+      for (int it = tid + UN * NT; it < patch_items; it += NT) {
+        const int pix = it / SLOTS, rr = udiv_magic(pix, a.pw_magic), px = pix - rr * PW;
+        half8 v, vl;
+        int dst;
+        bool live;
+        load_item(it, rr, px, n0, iy0, ix0, chunk, v, vl, dst, live);
+        put_item(v, vl, dst, live);
+      }
+    }
+  };
+
+  // ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (+32 for the upper half,
+  // MI355X_MICROARCH.md LDS table).  With PS/16 odd a group is conflict-free iff its 16 patch-pixel indices are
+  // distinct mod 16, so lanes are RANKED such that each group owns 16 consecutive logical pixels: one 16-pixel row
+  // segment (TW >= 16) or, for 8-wide maps, two 8-pixel rows 4/STRIDE apart (their patch rows are then
+  // 4 * RP = 8 (mod 16) pixels apart because the host keeps RP = 2 (mod 4)).  Only used when a 32-pixel block lies
+  // inside one sample (H*W >= 32); smaller maps keep the natural order the GAP butterfly relies on.
+  const bool rank_lanes = (tw_l + th_l) >= 5;
+  int pr = p;
+  if (rank_lanes) pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
+  const bool pair_rows = rank_lanes && tw_l == 3 && th_l >= 3;
+  // tile-independent part of the lane -> pixel map, packed: x[0:5) y[5:10) slot[10:18) sample[18:30) ok[30]
+  int base[WPB], lmap[WPB];
+#pragma unroll
+  for (int j = 0; j < WPB; ++j) {
+    const int m = (wp * WPB + j) * 32 + pr;
+    const bool ok = m < m_valid;
+    const int mm = ok ? m : 0;
+    const int x = mm & (TW - 1);
+    int q = mm >> tw_l;  // row counter over (sample, y)
+    if (pair_rows) {
+      const int k = q & 7;
+      const int kp = STRIDE == 1 ? (((k & 1) << 2) | (k >> 1)) : ((k & 4) | ((k & 1) << 1) | ((k >> 1) & 1));
+      q = (q & ~7) | kp;
+    }
+    const int y = q & (TH - 1), sm = q >> th_l;
+    base[j] = DMA ? (sm * PH + y) * RP + x                        // DMA: patch pixel index of tap (0,0) (slots are swizzled per pixel)
+                  : ((sm * PH + y * STRIDE) * RP + x) * PS + h * 16;  // LDS byte offset of (pixel, tap (0,0), slot h)
+    lmap[j] = x | (y << 5) | (((mm & ((1 << (tw_l + th_l)) - 1)) >> 5) << 10) | (sm << 18) | ((ok ? 1 : 0) << 30);
+  }
+
+  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
+  auto issue_step = [&](int chunk, int g, int buf) {
+    const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
+    char *dst = wring + buf * NSPLIT * WCHUNK;
+    // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
+    // its own re-copies the last piece (same bytes to the same place: benign)
+#pragma unroll
+    for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+      for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
+        int pi = wave + k * NW;
+        pi = pi < NPIECE ? pi : NPIECE - 1;
+        glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
+      }
+  };
+  // weights that fit one step and one chunk stay resident in LDS for the life of the (persistent) workgroup
+  constexpr bool W_RESIDENT = NG == 1 && NCHUNK == 1;
+  // Cross-stage prefetch keeps ~UN*4 + 16 more VGPRs live through the MFMA loop.  It pays where the loop is short and
+  // there is no weight ring competing for registers / the vmcnt queue (the 32-channel layers, measured 0.70 -> 0.50 ms);
+  // the ring kernels lose more occupancy than they gain and load each stage's patch right before committing it.
+  constexpr bool PREFETCH = W_RESIDENT;
+  // Persistence (several tiles per workgroup) only where it pays: a real tile loop makes the compiler keep far more state
+  // live (64@32: 79 -> 168 VGPRs, 2 -> 1 workgroups per CU).  Ring kernels run exactly one tile per workgroup (grid.x = ntiles).
+  constexpr bool PERSIST = W_RESIDENT;
+  static_assert(!DMA || (W_RESIDENT && NSPLIT == 1 && STRIDE == 1 && !SC), "DMA staging: resident weights, stride 1, fast arithmetic");
+  if constexpr (W_RESIDENT) issue_step(0, 0, 0);
+
+  // residual prefetch registers (16 B per lane and quad pair, see pair16)
+  constexpr int NRES = WCB * WPB * 2 * NSPLIT;  // residual loads per lane
+  uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
+
+  // ---- DMA staging: UN LDS-DMA instructions per wave move one tile's patch; LDS position of item it is it * 16 bytes,
+  // item = (patch pixel q, position pos) holds channel slot pos ^ ((q >> PIXROW_L) & (SLOTS - 1)) ----
+  auto dma_patch = [&](int t, int buf) {
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    const int iy0 = (ty << th_l) - PAD, ix0 = (tx << tw_l) - PAD;
+    const int npiece = a.patch_bytes >> 10, npix = (1 << spw_l) * PH * PW;
+    char *dst = smem + buf * a.patch_bytes;
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      int piece = wave + k * NW;
+      piece = piece < npiece ? piece : npiece - 1;  // every wave issues exactly UN instructions (counted vmcnt); extras re-copy the last KiB
+      const int it = piece * 64 + lane;
+      const int q = it / SLOTS, pos = it & (SLOTS - 1);
+      const int sl = pos ^ ((q >> PIXROW_L) & (SLOTS - 1));
+      const int rr = udiv_magic(q, a.pw_magic), px = q - rr * PW;
+      const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool live = q < npix && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+      const char *src = live ? (const char *)a.x + ((((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + sl * 8) * 2
+                             : (const char *)a.zero + ((((int)blockIdx.x * NT + tid) * 16) & 0xFFF0);  // spread over the zero page: no hot line
+      glds16(src, dst + piece * 1024);
+    }
+  };
+
+  int t = blockIdx.x;
+  const int tstep = gridDim.x;
+  if (!DMA && PREFETCH && t < ntiles) issue_patch(t, 0);
+  int cur = 0;  // DMA: patch buffer the current tile reads
+  if constexpr (DMA) {
+    if (t < ntiles) dma_patch(t, 0);
+    // resident weights + first patch landed (each wave waits for its own LDS-DMA, the barrier publishes them)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  int lane16 = lane * 16;
+  PH_DECL;
+  for (; t < ntiles; t = PERSIST ? t + tstep : ntiles) {
+    PH_MARK(7);
+    // The tile loop must not become a reason to keep every tile-invariant address term in registers: without this the
+    // compiler hoists them all out of the loop (64@32: 79 -> 168 VGPRs, one workgroup per CU instead of two).  Passing the
+    // few base values through an empty asm makes everything derived from them loop-variant again.
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(base[j]));
+    asm volatile("" : "+v"(lane16));
+    int RPt = RP, HALFt = HALF;
+    asm volatile("" : "+s"(RPt), "+s"(HALFt));
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    int opix[WPB];  // output pixel index (flattened n,y,x) or -1
+    int gidx[WPB];  // gap partial-sum row (sample * nslots + slot) or -1
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+      const int lxj = lmap[j] & 31, lyj = (lmap[j] >> 5) & 31, lsl = (lmap[j] >> 10) & 255, lsj = (lmap[j] >> 18) & 4095;
+      const bool ok = (lmap[j] >> 30) && (n0 + lsj) < a.n;
+      const int oy = (ty << th_l) + lyj, ox = (tx << tw_l) + lxj;
+      opix[j] = ok ? ((((n0 + lsj) << hout_l) + oy) << hout_l) + ox : -1;
+      const int tile_in_sample = (ty << txs_l) + tx;
+      gidx[j] = ok ? (n0 + lsj) * a.gap_slots + ((tile_in_sample << (tw_l + th_l)) >> 5) + lsl : -1;
+    }
+    const int t_next = PERSIST ? t + tstep : ntiles;
+    // folded BN biases of this lane's output channels: issued here so the loads fly under the staging / MFMA phase
+    // (a load placed in the epilogue is waited for on the spot)
+    float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
+    auto load_biases = [&]() {
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+          if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+        }
+    };
+    // early (latency hidden under the MFMA phase, +16..32 live VGPRs) where registers are not the occupancy limiter;
+    // the stride-1 ring kernels load them at the epilogue (measured: 128@16 0.41 vs 0.48 ms)
+    constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || SC);
+    if constexpr (BIAS_EARLY) load_biases();
+
+    float16v acc[WCB][WPB];
+    float16v acc_sc[SCW][SPB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SCW; ++i)
+#pragma unroll
+      for (int j = 0; j < SPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
+
+    auto load_residual = [&]() {  // residual reads (uniform branch): clamped address when the pixel is invalid
+      if (!a.res) return;
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) {
+          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+            if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
+          }
+        }
+    };
+    // what flies during the LAST weight steps of a chunk: the next stage's patch and, before the epilogue, the residual
+    auto prefetch_next = [&](int chunk) {
+      if constexpr (!PREFETCH) return;
+      if (chunk + 1 < NCHUNK) issue_patch(t, chunk + 1);
+      else if (t_next < ntiles) issue_patch(t_next, 0);
+      else {  // nothing follows: keep the number of outstanding loads identical (the counted waits depend on it)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          pv[u] = *(const half8 *)((const _Float16 *)a.x + (size_t)(tid & 255) * 8);
+          if constexpr (NSPLIT == 2) pvl[u] = pv[u];
+          pdst[u] = -1;
+        }
+      }
+      if (W_RESIDENT && chunk + 1 == NCHUNK) load_residual();
+    };
+    // loads in flight behind the ring's last counted wait of a chunk (prefetch_next): patch items (+ residual)
+    const int PF_PATCH = UN * NSPLIT;
+
+    bool all_ok = true;  // DMA: every lane of this wave stores (the counted wait at the end of the tile relies on it)
+    if constexpr (DMA) {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) all_ok = all_ok && __all(opix[j] >= 0);
+      load_residual();  // OLDER than the DMA below: waiting for it in the epilogue does not drain the DMA
+      // next tile's patch into the other buffer (all waves passed the previous tile's closing barrier, so nobody reads it);
+      // the last tile re-fetches itself so that the number of outstanding operations does not depend on the path
+      PH_MARK(0);
+      dma_patch(t_next < ntiles ? t_next : t, cur ^ 1);
+      PH_MARK(1);
+      const char *pb = smem + cur * a.patch_bytes;
+      if constexpr (ASM_PIPE) {
+        constexpr int NITEM = TAPS * KS, NR = WCB + WPB;
+        const uint32_t wb = lds0 + (uint32_t)(wring - smem) + (wc * WCB) * 1024 + lane16;
+        const uint32_t pl = lds0 + cur * a.patch_bytes;
+        half8 fa[3][WCB], fb[3][WPB];
+        uint32_t rowa[WPB], hs[WPB];  // per tap: byte address of the pixel, (h * 16) ^ (swizzle << 4)
+        auto issue = [&](auto ic) {
+          constexpr int item = decltype(ic)::value, sl = item % 3, tt = item / KS, ks = item % KS;
+          if constexpr (ks == 0) {
+            constexpr int dy = tt / 3, dx = tt % 3;
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) {
+              const int q = base[j] + dy * RPt + dx;
+              rowa[j] = pl + q * (KC * 2);
+              hs[j] = (h * 16) ^ (((q >> PIXROW_L) & (SLOTS - 1)) << 4);
+            }
+          }
+          static_for<WCB>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, off = ((tt * KS + ks) * CBT + i) * 1024;
+            lds_read128<off & 0xFFFF>(fa[sl][i], wb + (off & ~0xFFFF));
+          });
+          static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        static_for<NITEM>([&](auto ic) {
+          constexpr int item = decltype(ic)::value, sl = item % 3;
+          if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
+          constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
+          lds_wait<younger>();
+#pragma unroll
+          for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) lds_touch(fb[sl][j]);
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+        });
+      } else {
+        half8 af[2][WCB], bf[2][WPB];
+        auto load_frags = [&](int item, int sl) {
+          const int tt = item / KS, ks = item - tt * KS;
+          const int dy = tt / 3, dx = tt - dy * 3;
+#pragma unroll
+          for (int i = 0; i < WCB; ++i) af[sl][i] = *(const half8 *)(wring + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) {
+            const int q = base[j] + dy * RPt + dx;
+            const int sw = (q >> PIXROW_L) & (SLOTS - 1);
+            bf[sl][j] = *(const half8 *)(pb + q * (KC * 2) + (((ks * 2 + h) ^ sw) << 4));
+          }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int item = 0; item < TAPS * KS; ++item) {
+          const int cb = item & 1;
+          if (item + 1 < TAPS * KS) load_frags(item + 1, cb ^ 1);
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][i], bf[cb][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      PH_MARK(3);
+    }
+    for (int chunk = 0; chunk < (DMA ? 0 : NCHUNK); ++chunk) {
+      if constexpr (!PREFETCH) issue_patch(t, chunk);
+      PH_MARK(0);
+      commit_patch(t, chunk);  // registers -> LDS (the compiler waits for exactly these loads here)
+      PH_MARK(1);
+      if constexpr (!W_RESIDENT) {
+        issue_step(chunk, 0, 0);
+#pragma unroll
+        for (int d = 1; d < PFD; ++d)
+          if (d < NG) issue_step(chunk, d, d);
+      }
+      if constexpr (NBUF > 1) {
+        // step 0 must have landed; the PFD-1 younger steps may stay in flight.  LDS-DMA data is ordered for another
+        // wave's ds_read only by the ISSUING wave's vmcnt followed by a barrier; the patch ds_writes need lgkmcnt(0).
+        constexpr int INFL0 = (PFD - 1 < NG - 1 ? PFD - 1 : NG - 1) * PPW;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL0) : "memory");
+      } else if constexpr (W_RESIDENT) {
+        // The resident weights' LDS-DMA is older than the first patch loads, so the wait commit_patch needed for those
+        // already covers it.  Only the patch ds_writes must be visible: lgkmcnt(0) + raw barrier -- a __syncthreads()
+        // would add vmcnt(0) and expose the previous tile's epilogue STORES (vmcnt counts stores on CDNA4).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        prefetch_next(chunk);  // single weight step: the whole MFMA phase + epilogue hide these loads
+      } else {
+        __syncthreads();  // drains vmcnt (LDS-DMA landed) and makes the patch visible
+        prefetch_next(chunk);
+      }
+      PH_MARK(2);
+
+      int cur_buf = 0;
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) {
+        char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
+        if constexpr (NBUF > 1) {
+          // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
+          if (g + PFD < NG) {
+            int nb = cur_buf + PFD;
+            if (nb >= NBUF) nb -= NBUF;
+            issue_step(chunk, g + PFD, nb);
+          }
+          // after the LAST weight step of this chunk has been issued: start the next stage's loads (they are younger than
+          // every ring operation still needed, so the counted waits below simply add them)
+          if (g + PFD == NG - 1 || (NG <= PFD && g == 0)) prefetch_next(chunk);
+        }
+        // Fragment reads run ONE (tap, k-step) ahead of the MFMAs that consume them (register double buffer), so the
+        // ds_read latency of item i+1 hides under the MFMAs of item i instead of serialising read -> wait -> MFMA.
+        auto tap_off = [&](int tt) -> int {
+          const int tp = g * GT + tt;
+          if (TAPS != 9) return 0;
+          const int te = (SC && tp == TAPS) ? 4 : tp;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+          const int dy = te / 3, dx = te - dy * 3;
+          return STRIDE == 2 ? (dy * RPt + (dx & 1) * HALFt + (dx >> 1)) * PS : (dy * RPt + dx) * PS;
+        };
+        if constexpr (ASM_PIPE) {
+          // three fragment slots: the reads of items i+1 and i+2 are in flight while the MFMAs of item i run
+          constexpr int NITEM = GT * KS, NR = WCB + WPB;
+          const uint32_t wb = lds0 + (uint32_t)(wcur - smem) + (wc * WCB) * 1024 + lane16;
+          half8 fa[3][WCB], fb[3][WPB];
+          uint32_t pbt[WPB];
+          auto issue = [&](auto ic) {
+            constexpr int item = decltype(ic)::value, sl = item % 3, tt = item / KS, ks = item % KS;
+            if constexpr (ks == 0) {
+              const int toff = tap_off(tt);
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) pbt[j] = lds0 + base[j] + toff;
+            }
+            static_for<WCB>([&](auto ii) {
+              constexpr int i = decltype(ii)::value, off = ((tt * KS + ks) * CBT + i) * 1024;
+              lds_read128<off & 0xFFFF>(fa[sl][i], wb + (off & ~0xFFFF));
+            });
+            static_for<WPB>([&](auto jj) { lds_read128<ks * 32>(fb[sl][decltype(jj)::value], pbt[decltype(jj)::value]); });
+          };
+          issue(std::integral_constant<int, 0>{});
+          if constexpr (NITEM > 1) issue(std::integral_constant<int, 1>{});
+          static_for<NITEM>([&](auto ic) {
+            constexpr int item = decltype(ic)::value, sl = item % 3;
+            if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
+            constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
+            lds_wait<younger>();
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) lds_touch(fb[sl][j]);
+            const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+            if (is_sc) {
+              if constexpr (SC) {
+#pragma unroll
+                for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                  for (int j = 0; j < WPB; ++j) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc_sc[i][j], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+            }
+          });
+        } else {
+        half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
+        auto load_frags = [&](int item, int sl) {
+          const int tt = item / KS, ks = item - tt * KS;
+          const int toff = tap_off(tt);
+#pragma unroll
+          for (int i = 0; i < WCB; ++i) {
+            af[sl][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+            if constexpr (NSPLIT == 2) afl[sl][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+          }
+#pragma unroll
+          for (int j = 0; j < WPB; ++j) {
+            bf[sl][j] = *(const half8 *)(patch + base[j] + toff + ks * 32);
+            if constexpr (NSPLIT == 2) bfl[sl][j] = *(const half8 *)(patch + a.patch_bytes + base[j] + toff + ks * 32);
+          }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int item = 0; item < GT * KS; ++item) {
+          const int cur = item & 1;
+          if (item + 1 < GT * KS) load_frags(item + 1, cur ^ 1);
+          const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+          if (is_sc) {
+            if constexpr (SC) {
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                  if constexpr (NSPLIT == 2) {
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
+                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
+                  }
+                }
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < WCB; ++i)
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                if constexpr (NSPLIT == 2) {
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                }
+              }
+          }
+        }
+        }  // !ASM_PIPE
+        PH_MARK(3);
+        if constexpr (NBUF > 1) {
+          if (g + 1 < NG) {
+            // step g+1 must have landed; steps g+2 .. min(g+PFD, NG-1) may stay in flight, and so may the next stage's
+            // loads once they have been issued (they are younger): counted vmcnt + raw barrier (__syncthreads() would
+            // drain the whole queue with vmcnt(0))
+            const int last = g + PFD < NG - 1 ? g + PFD : NG - 1;
+            const int infl = last - (g + 1);
+            const bool pf_out = PREFETCH && g + PFD >= NG - 1;  // prefetch_next already issued
+            const bool with_res = false;  // ring kernels read the residual in the epilogue (register budget)
+            if (!pf_out) {
+              if (infl >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+              else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
+              else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else if (with_res) {  // infl == 0 here: every ring step has been issued before the prefetch
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT + NRES) : "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT) : "memory");
+            }
+            if (++cur_buf == NBUF) cur_buf = 0;
+          }
+        }
+      }
+      PH_MARK(4);
+      // everyone is done reading this stage's patch / weights before the next commit overwrites them
+      if (chunk + 1 < NCHUNK) __builtin_amdgcn_s_barrier();
+      PH_MARK(4);
+    }
+    (void)PF_PATCH;
+  // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
+  if constexpr (!BIAS_EARLY) load_biases();
+  if constexpr (!W_RESIDENT) {
+    if (a.res) {  // all residual reads together (16 B per lane and quad pair), clamped address when the pixel is invalid
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) {
+          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+            if constexpr (NSPLIT == 2) resl[i][j][qq] = *(const uint4v *)((const char *)((const _Float16 *)a.res + o + 16 * qq) + a.res_lo_off);
+          }
+        }
+    }
+  }
+  conv_epilogue<COUT, CT, WCB, WPB, SC, NSPLIT>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
     // the next tile's commit overwrites the patch: every wave must be done reading it (and the GAP / stores above
     // do not touch LDS)
-    if (t_next < ntiles) __builtin_amdgcn_s_barrier();
+    PH_MARK(5);
+    if constexpr (DMA) {
+      if (t_next < ntiles) {
+        // the next tile's patch (this wave's DMA share) has landed, and -- after the barrier -- every wave is done reading the
+        // current buffer.  The output stores above are younger than the DMA and may stay in flight when their number is known.
+        if (a.gap || !all_ok) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WCB * WPB * 2) : "memory");
+        cur ^= 1;
+      }
+    } else if (t_next < ntiles) __builtin_amdgcn_s_barrier();
+    PH_MARK(6);
+  }
+  PH_FLUSH((CIN / 32) + (STRIDE == 2 ? 8 : 0));
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Weight-ring conv with LDS-DMA patch staging (fast arithmetic; the 64..256-channel layers of the 128x128 model).
+// Same tiling, weight packing, lane ranking and epilogue as conv_mfma_kernel, but
+//   * the input patch of a stage (tile, 32/64-channel chunk) is written by LDS-DMA into one of two unpadded,
+//     XOR-swizzled buffers (see the DMA mode of conv_mfma_kernel) while the previous stage computes: no register
+//     staging, no commit phase, a whole stage of patch traffic in flight;
+//   * vmcnt retires in order, so a wave that had both kinds of DMA in its queue would drain the long-lived patch DMA
+//     at every weight-step wait.  The waves therefore split the ROLES: the first half issues the weight ring (and
+//     waits for it every step), the second half issues the patch pieces (and waits once per stage).  All waves compute;
+//   * the weight ring runs continuously across chunks and tiles (no drain / refill per chunk), workgroups are
+//     persistent over tiles, fragment reads are asm-pipelined (lds_read128).
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW>
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_kernel(const ConvArgs a) {
+  constexpr int TAPS = 9, NSPLIT = 1;
+  constexpr int NCHUNK = CIN / KC, KS = KC / 16, SLOTS = KC / 8, PIXROW_L = KC == 64 ? 1 : 2;
+  constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NW = WAVES_C * WAVES_P, NT = 64 * NW;
+  constexpr int TT = TAPS + (SC ? 1 : 0), NG = TT / GT;
+  constexpr int WCHUNK = GT * KS * CBT * 1024, NBUF = RB, PFD = RB - 1, NPIECE = WCHUNK / 1024;
+  constexpr int NWR = NW / 2, NWP = NW - NWR;    // ring waves [0, NWR), patch waves [NWR, NW)
+  constexpr int PPWR = (NPIECE + NWR - 1) / NWR;  // ring LDS-DMA instructions per ring wave and step
+  constexpr int PPS = (UNP + NG - 1) / NG;        // patch pieces a patch wave issues per weight step
+  constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
+  static_assert(CIN % KC == 0 && (KC == 32 || KC == 64) && TT % GT == 0 && COUT % CT == 0, "tiling");
+  static_assert(NG >= 2 && RB >= 2 && RB <= 4 && PFD <= NG && NW >= 2, "ring");
+  static_assert(!SC || STRIDE == 2, "shortcut rides on stride-2 convs");
+  static_assert(WCHUNK <= 65536, "fragment offsets are ds_read immediates");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *ring = smem + 2 * a.patch_bytes;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+  const int p = lane & 31, h = lane >> 5;
+  const bool ring_wave = wave < NWR;
+  const int lane16 = lane * 16;
+
+  const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l, hout_l = a.hout_l, hin_l = a.hin_l;
+  const int TW = 1 << tw_l, TH = 1 << th_l, Hin = 1 << hin_l;
+  const int txs_l = hout_l - tw_l, tys_l = hout_l - th_l;
+  const int PH = a.ph, PW = a.pw, RP = a.rp, HALF = a.half;
+  const int m_valid = 1 << (tw_l + th_l + spw_l);
+  const int ctile = blockIdx.y, ntiles = a.ntiles;
+  auto tile_decode = [&](int t, int &tx, int &ty, int &n0) {  // XCD-contiguous tile order, see conv_mfma_kernel
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    tx = mt & ((1 << txs_l) - 1);
+    ty = (mt >> txs_l) & ((1 << tys_l) - 1);
+    n0 = (mt >> (txs_l + tys_l)) << spw_l;
+  };
+
+  // lane -> pixel map (lane ranking: see conv_mfma_kernel); base[j] = patch pixel index of tap (0,0)
+  const bool rank_lanes = (tw_l + th_l) >= 5;
+  int pr = p;
+  if (rank_lanes) pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
+  const bool pair_rows = rank_lanes && tw_l == 3 && th_l >= 3;
+  int base[WPB], lmap[WPB];
+#pragma unroll
+  for (int j = 0; j < WPB; ++j) {
+    const int m = (wp * WPB + j) * 32 + pr;
+    const bool ok = m < m_valid;
+    const int mm = ok ? m : 0;
+    const int x = mm & (TW - 1);
+    int q = mm >> tw_l;
+    if (pair_rows) {
+      const int k = q & 7;
+      const int kp = STRIDE == 1 ? (((k & 1) << 2) | (k >> 1)) : ((k & 4) | ((k & 1) << 1) | ((k >> 1) & 1));
+      q = (q & ~7) | kp;
+    }
+    const int y = q & (TH - 1), sm = q >> th_l;
+    base[j] = (sm * PH + y * STRIDE) * RP + x;
+    lmap[j] = x | (y << 5) | (((mm & ((1 << (tw_l + th_l)) - 1)) >> 5) << 10) | (sm << 18) | ((ok ? 1 : 0) << 30);
+  }
+
+  // ---- weight ring: global step sequence (chunk, g) cycles over the chunks whatever the tile ----
+  int t = blockIdx.x;
+  const int tstep = gridDim.x;
+  if (t >= ntiles) return;
+  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCHUNK * NG;
+  int ci = 0, gi = 0, slot_wr = 0;
+  int ahead = 0;  // ring steps issued and not yet computed (the current one included)
+  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
+  auto issue_ring = [&]() {  // next ring step, if any is left (all waves keep the counters, ring waves move the data)
+    if (steps_to_issue <= 0) return false;
+#ifdef KO_RING
+    if (false) {
+#else
+    if (ring_wave) {
+#endif
+      const char *src = wsrc + (size_t)(ci * TT + gi * GT) * (KS * CBT * 1024);
+      char *dst = ring + slot_wr * WCHUNK;
+#pragma unroll
+      for (int k = 0; k < PPWR; ++k) {
+        int pi = wave + k * NWR;
+        pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
+        glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+      }
+    }
+    --steps_to_issue;
+    ++ahead;
+    if (++gi == NG) { gi = 0; if (++ci == NCHUNK) ci = 0; }
+    if (++slot_wr == NBUF) slot_wr = 0;
+    return true;
+  };
+
+  // ---- patch pieces (patch waves): LDS position of item it is it * 16 bytes; item = (patch pixel q = row * RP + col,
+  // position pos) holds channel slot pos ^ ((q >> PIXROW_L) & (SLOTS - 1)); stride 2 keeps even / odd columns in halves ----
+  const int npiece = a.patch_bytes >> 10;
+  auto dma_piece = [&](int tp, int chunk, int buf, int k) {
+    const int piece = (wave - NWR) + k * NWP;
+    if (piece >= npiece) return;  // wave-uniform; patch waves wait with vmcnt(0), nothing counts their instructions
+#ifdef KO_PATCH
+    return;
+#endif
+    int tx, ty, n0;
+    tile_decode(tp, tx, ty, n0);
+    const int iy0 = ((ty << th_l) * STRIDE) - 1, ix0 = ((tx << tw_l) * STRIDE) - 1;
+    const int it = piece * 64 + lane;
+    const int q = it / SLOTS, pos = it & (SLOTS - 1);
+    const int sl = pos ^ ((q >> PIXROW_L) & (SLOTS - 1));
+    const int rr = udiv_magic(q, a.rp_magic), col = q - rr * RP;
+    const int px = STRIDE == 2 ? (col < HALF ? 2 * col : 2 * (col - HALF) + 1) : col;
+    const int s = udiv_magic(rr, a.ph_magic), py = rr - s * PH;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool live = s < (1 << spw_l) && px < PW && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin && (n0 + s) < a.n;
+    const char *src = live ? (const char *)a.x + ((((((size_t)(n0 + s) << hin_l) + iy) << hin_l) + ix) * CIN + chunk * KC + sl * 8) * 2
+                           : (const char *)a.zero + ((((int)blockIdx.x * NT + tid) * 16) & 0xFFF0);
+    glds16(src, smem + buf * a.patch_bytes + piece * 1024);
+  };
+
+  // ---- prologue: first stage's patch, first PFD ring steps ----
+  if (!ring_wave) {
+#pragma unroll
+    for (int k = 0; k < UNP; ++k) dma_piece(t, 0, 0, k);
+  }
+#pragma unroll
+  for (int d = 0; d < PFD; ++d) issue_ring();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  int cur = 0, slot_rd = 0;
+  uint4v resv[WCB][WPB][2], resl[1][1][2];
+  for (; t < ntiles; t += tstep) {
+    int tx, ty, n0;
+    tile_decode(t, tx, ty, n0);
+    int opix[WPB], gidx[WPB];
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+      const int lxj = lmap[j] & 31, lyj = (lmap[j] >> 5) & 31, lsl = (lmap[j] >> 10) & 255, lsj = (lmap[j] >> 18) & 4095;
+      const bool ok = (lmap[j] >> 30) && (n0 + lsj) < a.n;
+      const int oy = (ty << th_l) + lyj, ox = (tx << tw_l) + lxj;
+      opix[j] = ok ? ((((n0 + lsj) << hout_l) + oy) << hout_l) + ox : -1;
+      const int tile_in_sample = (ty << txs_l) + tx;
+      gidx[j] = ok ? (n0 + lsj) * a.gap_slots + ((tile_in_sample << (tw_l + th_l)) >> 5) + lsl : -1;
+    }
+    const int t_next = t + tstep;
+    float16v acc[WCB][WPB], acc_sc[SCW][SPB];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SCW; ++i)
+#pragma unroll
+      for (int j = 0; j < SPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_sc[i][j][r] = 0.f;
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+      const bool in_tile = chunk + 1 < NCHUNK;
+      const bool has_next = in_tile || t_next < ntiles;
+      const int tn = in_tile ? t : t_next, cn = in_tile ? chunk + 1 : 0;
+      const uint32_t pl = lds0 + cur * a.patch_bytes;
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) {
+        issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
+        if (!ring_wave && has_next) {
+#pragma unroll
+          for (int k = 0; k < PPS; ++k)
+            if (g * PPS + k < UNP) dma_piece(tn, cn, cur ^ 1, g * PPS + k);
+        }
+        // ---- MFMAs of this step: fragment reads two items ahead, counted waits ----
+        {
+          constexpr int NITEM = GT * KS, NR = WCB + WPB;
+          const uint32_t wb = lds0 + 2 * a.patch_bytes + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
+          half8 fa[3][WCB], fb[3][WPB];
+          uint32_t rowa[WPB], hs[WPB];
+          auto issue = [&](auto ic) {
+            constexpr int item = decltype(ic)::value, sl = item % 3, tt = item / KS, ks = item % KS;
+            if constexpr (ks == 0) {
+              const int tp = g * GT + tt;
+              const int te = (SC && tp == TAPS) ? 4 : tp;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+              const int dy = te / 3, dx = te - dy * 3;
+              const int tq = STRIDE == 2 ? dy * RP + (dx & 1) * HALF + (dx >> 1) : dy * RP + dx;
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) {
+                const int q = base[j] + tq;
+                rowa[j] = pl + q * (KC * 2);
+                hs[j] = (h * 16) ^ (((q >> PIXROW_L) & (SLOTS - 1)) << 4);
+              }
+            }
+#ifndef KO_READS
+            static_for<WCB>([&](auto ii) {
+              constexpr int i = decltype(ii)::value;
+              lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
+            });
+            static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
+#else
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) { half8 &r = fa[sl][i]; const uint32_t ad = wb; asm volatile("" : "=v"(r) : "v"(ad)); }
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) { half8 &r = fb[sl][j]; const uint32_t ad = rowa[j] + (hs[j] ^ (ks * 32)); asm volatile("" : "=v"(r) : "v"(ad)); }
+#endif
+          };
+          issue(std::integral_constant<int, 0>{});
+          if constexpr (NITEM > 1) issue(std::integral_constant<int, 1>{});
+          static_for<NITEM>([&](auto ic) {
+            constexpr int item = decltype(ic)::value, sl = item % 3;
+            if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
+            constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
+            lds_wait<younger>();
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+#pragma unroll
+            for (int j = 0; j < WPB; ++j) lds_touch(fb[sl][j]);
+            const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+            if (is_sc) {
+              if constexpr (SC) {
+#pragma unroll
+                for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                  for (int j = 0; j < WPB; ++j) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc_sc[i][j], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+            }
+          });
+        }
+        // ---- end of step: the next ring step has landed (ring waves; LDS-DMA is published by the issuing wave's vmcnt +
+        // a barrier); at the end of a stage also the next patch (patch waves) ----
+        // of the `ahead` issued steps this one is done and the next must have landed: the ahead - 2 younger ones may fly
+        // (anything else in the queue -- epilogue stores -- only makes the counted wait stricter)
+        if (ring_wave) {
+          if (PFD >= 3 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPWR) : "memory");
+          else if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (g == NG - 1) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#ifndef KO_BARRIER
+        asm volatile("s_barrier" ::: "memory");
+#endif
+        --ahead;
+        if (++slot_rd == NBUF) slot_rd = 0;
+      }
+      cur ^= 1;
+    }
+
+#ifdef KO_EPI
+    if (a.n < 0) {  // never true: keeps the accumulators alive
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) ((float16v *)a.y)[tid + i + j] = acc[i][j];
+    }
+    continue;
+#endif
+    // ---- epilogue (biases and residual are read here: the other workgroup of the CU covers the latency) ----
+    float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+        if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+      }
+    if (a.res) {
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j) {
+          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+        }
+    }
+    conv_epilogue<COUT, CT, WCB, WPB, SC, NSPLIT>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
   }
 }
 
@@ -1194,13 +1745,14 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
-  const int lds = NSPLIT * a.patch_bytes + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
+  const int patch_lds = (DMA ? 2 : NSPLIT) * a.patch_bytes;
+  const int lds = patch_lds + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1210,6 +1762,23 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   dim3 grid(grid_x, COUT / (32 * CBT));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_C * WAVES_P), lds, st, a);
+  return hipGetLastError();
+}
+
+template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW>
+static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t st) {
+  auto kern = conv_ring_dma_kernel<CIN, COUT, STRIDE, SC, KC, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UNP, MINW>;
+  constexpr int CBT = WCB * WAVES_C, NW = WAVES_C * WAVES_P;
+  const int lds = 2 * a.patch_bytes + RB * GT * (KC / 16) * CBT * 1024;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  if (lds > 160 * 1024 || (a.patch_bytes >> 10) > UNP * (NW - NW / 2)) return hipErrorInvalidValue;
+  dim3 grid(grid_x, COUT / (32 * CBT));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1291,16 +1860,45 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
 #ifndef CFG_BIG_WC
 #define CFG_BIG_WC 2
 #endif
-struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2]; };
+#ifndef CFG_64_DMA     // 64@32 stride-1: LDS-DMA double-buffered patch staging (fast arithmetic, maps >= 16 x 16)
+#define CFG_64_DMA 1
+#endif
+#ifndef CFG_64_DMA_UN  // LDS-DMA instructions per wave and tile: 10 x 34 pixels x 8 slots / (8 waves x 64 lanes) = 5.3
+#define CFG_64_DMA_UN 6
+#endif
+#ifndef CFG_BIG_DMA     // 128@16, 256@8 stride-1: ring kernel with LDS-DMA patch staging (conv_ring_dma_kernel), maps >= 8 x 8
+#define CFG_BIG_DMA 0
+#endif
+#ifndef CFG_BIG_DMA_WP  // ... waves along pixels (x CFG_BIG_WC = waves per workgroup): 4 -> 128-pixel tiles, 8 -> 256
+#define CFG_BIG_DMA_WP 4
+#endif
+#ifndef CFG_BIG_DMA_WPB
+#define CFG_BIG_DMA_WPB 1
+#endif
+#ifndef CFG_BIG_DMA_UNP   // patch pieces per patch wave and stage (upper bound, checked at launch)
+#define CFG_BIG_DMA_UNP 7
+#endif
+#ifndef CFG_BIG_DMA_MINW  // min waves per SIMD (VGPR cap)
+#define CFG_BIG_DMA_MINW 4
+#endif
+#ifndef CFG_BIG_DMA_RB  // ring depth, 128@16
+#define CFG_BIG_DMA_RB 2
+#endif
+#ifndef CFG_256_DMA_RB  // ring depth, 256@8 (its 4-sample patch buffers leave room for 3 slots at most)
+#define CFG_256_DMA_RB (CFG_BIG_DMA_RB > 3 ? 3 : CFG_BIG_DMA_RB)
+#endif
+// dma (fast arithmetic only): 0 none, 1 resident-weights DMA mode of conv_mfma_kernel, 2 conv_ring_dma_kernel with
+// its own pixel tiling {wpb, wp}_dma (the cout tiling, KC and GT -- i.e. the weight packing -- are shared)
+struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_dma, wp_dma; };
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
     {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
-    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}},
+    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA},
     {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
-    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
     {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
-    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}},
+    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
     {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
@@ -1312,7 +1910,9 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
     if (r.cin == cin && r.cout == cout && r.stride == stride) {
       out->kc = r.kc[exact ? 1 : 0];
       out->ct = 32 * r.wcb * r.wc;
+      out->dma = exact ? 0 : r.dma;
       out->mt = 32 * r.wpb * r.wp;
+      out->mt_dma = r.dma == 2 ? 32 * r.wpb_dma * r.wp_dma : out->mt;
       out->gt = r.gt[exact ? 1 : 0];
       return true;
     }
@@ -1323,12 +1923,22 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 // UNF / UNE: patch items per lane prefetched in registers (fast / exact), sized for the 128x128 model's tiles
 #define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)                                    \
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
-    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF, UNF, MWF>(a, grid_x, extra_lds, st); \
-    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE, UNE, 1>(a, grid_x, extra_lds, st);           \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF, UNF, MWF, false>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st);           \
   }
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+#if CFG_BIG_DMA
+  if (dma && !exact && cin == 128 && cout == 128 && stride == 1)
+    return launch_ring_dma_t<128, 128, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_BIG_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW>(a, grid_x, st);
+  if (dma && !exact && cin == 256 && cout == 256 && stride == 1)
+    return launch_ring_dma_t<256, 256, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_256_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW>(a, grid_x, st);
+#endif
+#if CFG_64_DMA
+  if (dma && !exact && cin == 64 && cout == 64 && stride == 1)
+    return launch_conv_t<64, 64, 1, 9, false, 64, 1, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 9, 1, CFG_64_DMA_UN, CFG_S1_MINW, true>(a, grid_x, extra_lds, st);
+#endif
   CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
   CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)

@@ -14,7 +14,8 @@ namespace mlt {
 // With has_sc the block's 1x1 stride-2 projection shortcut is stored as one extra "tap" after the 9 conv taps.
 struct PackedConv {
   int cin = 0, cout = 0, taps = 0, stride = 1;
-  int kc = 0, ct = 0, mt = 0, gt = 0;  // from mlt_conv_cfg(): cin chunk, couts / pixels per workgroup, taps per step
+  int kc = 0, ct = 0, mt = 0, gt = 0;  // from mlt_conv_cfg(): cin chunk, couts / pixels per tile, taps per step
+  int dma = 0, mt_dma = 0;             // LDS-DMA staging variant (0 none, 1 resident weights, 2 weight ring) and its pixels per workgroup
   bool has_sc = false;
   bool exact = false;          // w holds a hi plane followed by a lo plane (fp16 pair per weight)
   size_t plane_halves = 0;     // halves per plane

@@ -34,6 +34,7 @@ class SplitPredictor {
     for (int &h : cfg.head_index) h = -1;  // reference defaults: element [2] for 128, [0] otherwise (EncCu.cpp:913-919)
     cfg.max_batch = 1;
     cfg.flags = flags;
+    cfg.guard_margin = 0.f;  // default threshold when MLT_FLAG_DECISION_GUARD is set
     m_mask = sizeMask ? sizeMask : MLT_SIZE_128;
     const int rc = mlt_init(&cfg, &m_ctx);
     if (rc != MLT_OK) {

@@ -48,6 +48,12 @@ enum {
  * fp16 rounding is not averaged away by the global pooling, and these models are 5-65x cheaper). */
 #define MLT_FLAG_EXACT_128 0x1u
 #define MLT_FLAG_FAST_SMALL 0x2u
+/* Decision guard for sizes running the fast arithmetic: mlt_predict / mlt_predict_batch (host-pointer entry points)
+ * re-evaluate with the exact arithmetic every CU whose decision-head top-2 logit margin is below
+ * mlt_config.guard_margin and return the exact logits / split for it.  The split mode handed to
+ * EncModeCtrl::setNewModeList is then the one ~fp32 arithmetic gives, at fast throughput for all other CUs.
+ * Costs a second (exact) copy of the weights on the device. */
+#define MLT_FLAG_DECISION_GUARD 0x4u
 
 typedef struct mlt_ctx mlt_ctx;
 
@@ -62,6 +68,8 @@ typedef struct mlt_config {
                              element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
   int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
   uint32_t flags;         /* MLT_FLAG_* bits, 0 = defaults */
+  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 0.02
+                             (about 7x the largest fast-mode logit error measured on the degenerate fixtures) */
 } mlt_config;
 
 /* Create a context: selects the device, allocates workspaces, loads + folds + packs weights

@@ -1,0 +1,39 @@
+"""Debug: per-phase cycle breakdown of conv_mfma_kernel (build with -DMLT_PHASE_TIMING).  GPU box only.
+usage: python scripts/phase_timing.py [batch]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mltcnn_pkg  # noqa: E402
+
+pkg = mltcnn_pkg.load()
+out = os.path.join(os.path.dirname(pkg.build.__file__), "_variants", "lib_phase.so")
+pkg.build.build_lib(force=True, defines=["MLT_PHASE_TIMING=1"], out=out)
+os.environ["MLT_LIB_PATH"] = out
+import torch  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+blob = pkg.weights.synthetic_blob(0, 1)
+m = pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob}, max_batch=n)
+org, pred = pkg.synth.make_patches_bulk(128, n, 3)
+poc, qp = pkg.synth.make_scalars(n, 3)
+dev = torch.device("cuda:0")
+t = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+split = torch.empty(n, dtype=torch.int32, device=dev)
+lg = torch.empty(n, 9, dtype=torch.float32, device=dev)
+lib = C.CDLL(out)
+buf = (C.c_ulonglong * 128)()
+for it in range(3):
+    m.predict_batch_device(n, 128, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), split.data_ptr(), lg.data_ptr())
+    m.synchronize()
+    lib.mlt_debug_phase_read(buf, 1)
+names = ["wait/issue patch (DMA: residual issue)", "commit (DMA: dma issue)", "barrier+pf issue", "mfma loop", "step wait+barrier", "epilogue", "tile barrier", "tile setup"]
+for kid in range(16):
+    row = [buf[kid * 8 + i] for i in range(8)]
+    tot = sum(row)
+    if not tot:
+        continue
+    print(f"kernel id {kid} (cin={32 * (kid & 7)}, stride={2 if kid & 8 else 1}): total {tot / 1e6:.1f} Mcycles (wave 0, all WGs, all launches)")
+    for nm, v in zip(names, row):
+        print(f"   {nm:40s} {100.0 * v / tot:5.1f} %")

@@ -10,10 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
-    "bias_early": [],
-    "bias_late": ["CFG_BIAS_EARLY=0"],
-    "bias_early2": [],
-    "bias_late2": ["CFG_BIAS_EARLY=0"],
+    "ko_all": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1'],
+    "ko_all_reads": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_READS=1'],
+    "ko_all_epi": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_EPI=1'],
+    "ko_all_reads_epi": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_READS=1', 'KO_EPI=1'],
+    "ko_reads_only": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_READS=1'],
+    "ko_epi_only": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_EPI=1'],
 }
 
 

@@ -32,6 +32,7 @@ def test_abi_version_and_logit_counts(lib):
 def test_config_struct_layout(pkg):
     # must match `struct mlt_config` in include/mltcnn.h (x86-64 SysV)
     assert C.sizeof(pkg.capi.MltConfig) == 48
+    assert pkg.capi.MltConfig.guard_margin.offset == 44
     assert pkg.capi.MltConfig.weights_dir.offset == 8
     assert pkg.capi.MltConfig.head_index.offset == 20
     assert C.sizeof(pkg.capi.MltKernelTime) == 72

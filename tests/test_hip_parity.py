@@ -142,6 +142,40 @@ def test_batch_split_invariance_and_determinism(gpu):
     m.close()
 
 
+def test_decision_guard_replaces_near_ties_with_exact_results(gpu):
+    """MLT_FLAG_DECISION_GUARD: CUs whose fast decision-head margin is under the threshold come back with the
+    exact-mode logits / split (bit-identical to an exact-mode context), all others keep the fast result."""
+    pkg = gpu
+    size, n = 128, 40
+    blob = pkg.weights.synthetic_blob(0, 21)
+    org, pred = pkg.synth.make_patches(size, n, 17)
+    o2, p2 = pkg.synth.make_patches(size, 4, 18, pkg.synth.KIND_SATURATED)
+    org, pred = np.concatenate([org, o2]), np.concatenate([pred, p2])
+    n += 4
+    poc, qp = pkg.synth.make_scalars(n, 17)
+    fast, exact = _ctx(pkg, size, blob), _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
+    s_f, l_f = fast.predict_batch(org, pred, poc, qp)
+    s_e, l_e = exact.predict_batch(org, pred, poc, qp)
+    head = slice(5, 9)  # CTU model decision head = element [2] (EncCu.cpp:913-915)
+    top2 = np.sort(l_f[:, head], axis=1)
+    margins = top2[:, -1] - top2[:, -2]
+    thr = float(np.median(margins))
+    flagged = margins < np.float32(thr)
+    assert 0 < flagged.sum() < n
+    g = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_DECISION_GUARD, guard_margin=thr)
+    s_g, l_g = g.predict_batch(org, pred, poc, qp)
+    assert np.array_equal(l_g[flagged], l_e[flagged]) and np.array_equal(s_g[flagged], s_e[flagged])
+    assert np.array_equal(l_g[~flagged], l_f[~flagged]) and np.array_equal(s_g[~flagged], s_f[~flagged])
+    s_only, none = g.predict_batch(org, pred, poc, qp, want_logits=False)
+    assert none is None and np.array_equal(s_only, s_g)
+    for i in (int(np.flatnonzero(flagged)[0]), int(np.flatnonzero(~flagged)[0])):  # EncCu call-site entry point
+        for _ in range(2):  # second call replays the captured graph after the exact pass grew the workspace
+            s1, l1 = g.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+            assert s1 == s_g[i] and np.array_equal(l1, l_g[i])
+    for m in (fast, exact, g):
+        m.close()
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)
