@@ -88,6 +88,14 @@ template <int N> __device__ __forceinline__ void lds_wait() {
 }
 __device__ __forceinline__ void lds_touch(half8 &v) { asm volatile("" : "+v"(v)); }  // orders the consumer after lds_wait
 
+// Phase stagger for persistent kernels: identical workgroups started together stay in lock-step chip-wide, so every CU
+// reaches its memory-heavy phase (epilogue residual reads + stores) at the same moment and the launch takes
+// T_compute + T_memory instead of max(...).  Delaying workgroup b by (b mod phases) * units * ~4 us spreads the phases.
+__device__ __forceinline__ void stagger_start(int phases, int units) {
+  const int k = ((int)blockIdx.x % phases) * units;
+  for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // n / d for d >= 2 with magic = ceil(2^32 / d); exact while n * d < 2^32 (patch indices are < 2^16)
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
 
@@ -133,16 +141,25 @@ __device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // i
 // fp32 GAP partial sums; SC: second output (projection shortcut, no ReLU).  The caller has loaded the biases (bq / bsq)
 // and, when a.res is set, the residual (resv / resl) into registers.
 // ---------------------------------------------------------------------------------------------
+// bias_lds != nullptr: the cout tile's biases ([CT] floats, shortcut biases behind them) are read from LDS one
+// 32-channel block at a time instead of from bq / bsq (fewer live registers).
 template <int COUT, int CT, int WCB, int WPB, bool SC, int NSPLIT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int wc, int h, int p, const int (&opix)[WPB], const int (&gidx)[WPB],
                                               float16v (&acc)[WCB][WPB], float16v (&acc_sc)[SC ? WCB : 1][SC ? WPB : 1],
                                               const float4v (&bq)[WCB][4], const float4v (&bsq)[SC ? WCB : 1][4],
                                               const uint4v (&resv)[WCB][WPB][2],
-                                              const uint4v (&resl)[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2]) {
+                                              const uint4v (&resl)[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2],
+                                              const float *bias_lds = nullptr) {
   const int gl = a.gap_l;  // log2(lanes that share one sample in a 32-pixel block): 0, 2, 4 or 5
 #pragma unroll
   for (int i = 0; i < WCB; ++i) {
     const int cbase = ctile * CT + (wc * WCB + i) * 32 + 4 * h;
+    float4v bi[4], bsi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bi[q] = bias_lds ? *(const float4v *)(bias_lds + (wc * WCB + i) * 32 + 4 * h + 8 * q) : bq[i][q];
+      if constexpr (SC) bsi[q] = bias_lds ? *(const float4v *)(bias_lds + CT + (wc * WCB + i) * 32 + 4 * h + 8 * q) : bsq[i][q];
+    }
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
       const bool ok = opix[j] >= 0;
@@ -161,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
           const int q = 2 * qq + k;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float x = acc[i][j][4 * q + e] * a.acc_scale + bq[i][q][e];
+            float x = acc[i][j][4 * q + e] * a.acc_scale + bi[q][e];
             if (a.res) {
               x += (float)(k ? rb[e] : ra[e]);
               if constexpr (NSPLIT == 2) x += (float)(k ? rlb[e] : rla[e]);
@@ -171,7 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
             hq[q][e] = (_Float16)x;
             hl[q][e] = (_Float16)(x - (float)hq[q][e]);
             if constexpr (SC) {
-              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsq[i][q][e];
+              const float vs = acc_sc[i][j][4 * q + e] * a.acc_scale + bsi[q][e];
               sq[q][e] = (_Float16)vs;
               sl[q][e] = (_Float16)(vs - (float)sq[q][e]);
             }
@@ -900,14 +917,22 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 //   * the weight ring runs continuously across chunks and tiles (no drain / refill per chunk), workgroups are
 //     persistent over tiles, fragment reads are asm-pipelined (lds_read128).
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_kernel(const ConvArgs a) {
+//   * NWL > 0: the LDS-DMA is issued by NWL extra LOADER waves that do nothing else (first half: weight ring, second
+//     half: patch).  The compute waves' vmcnt queues then hold only their own residual prefetch and output stores, so
+//     the residual can be prefetched a chunk ahead and a store never sits in front of a ring wait; NWL == 0: the
+//     compute waves double as loaders (first half ring, second half patch).
+//   * FD: fragment reads run FD (1 or 2) items ahead of the MFMAs (FD + 1 register slots of WCB + WPB fragments).
+template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW, int NWL, int FD>
+__global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_ring_dma_kernel(const ConvArgs a) {
   constexpr int TAPS = 9, NSPLIT = 1;
   constexpr int NCHUNK = CIN / KC, KS = KC / 16, SLOTS = KC / 8, PIXROW_L = KC == 64 ? 1 : 2;
   constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NW = WAVES_C * WAVES_P, NT = 64 * NW;
   constexpr int TT = TAPS + (SC ? 1 : 0), NG = TT / GT;
   constexpr int WCHUNK = GT * KS * CBT * 1024, NBUF = RB, PFD = RB - 1, NPIECE = WCHUNK / 1024;
-  constexpr int NWR = NW / 2, NWP = NW - NWR;    // ring waves [0, NWR), patch waves [NWR, NW)
+  constexpr int NWR = NWL ? NWL / 2 : NW / 2, NWP = NWL ? NWL - NWR : NW - NWR;  // ring waves / patch waves
+  constexpr int LW0 = NWL ? NW : 0;              // first loader wave: ring waves [LW0, LW0 + NWR), patch waves follow
+  static_assert(NWL == 0 || NWL >= 2, "loader waves: at least one ring and one patch wave");
+  static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
   constexpr int PPWR = (NPIECE + NWR - 1) / NWR;  // ring LDS-DMA instructions per ring wave and step
   constexpr int PPS = (UNP + NG - 1) / NG;        // patch pieces a patch wave issues per weight step
   constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
@@ -923,7 +948,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % WAVES_C, wp = wave / WAVES_C;
   const int p = lane & 31, h = lane >> 5;
-  const bool ring_wave = wave < NWR;
+  const bool loader = NWL && wave >= NW;                         // a pure loader wave (no MFMA, no epilogue)
+  const bool ring_wave = wave >= LW0 && wave < LW0 + NWR;
+  const bool patch_wave = wave >= LW0 + NWR && wave < LW0 + NWR + NWP;
   const int lane16 = lane * 16;
 
   const int tw_l = a.tw_l, th_l = a.th_l, spw_l = a.spw_l, hout_l = a.hout_l, hin_l = a.hin_l;
@@ -967,6 +994,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
   int t = blockIdx.x;
   const int tstep = gridDim.x;
   if (t >= ntiles) return;
+#if defined(CFG_STAGGER_PHASES)
+  stagger_start(CFG_STAGGER_PHASES, CFG_STAGGER_UNITS);
+#endif
   int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCHUNK * NG;
   int ci = 0, gi = 0, slot_wr = 0;
   int ahead = 0;  // ring steps issued and not yet computed (the current one included)
@@ -982,7 +1012,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
       char *dst = ring + slot_wr * WCHUNK;
 #pragma unroll
       for (int k = 0; k < PPWR; ++k) {
-        int pi = wave + k * NWR;
+        int pi = (wave - LW0) + k * NWR;
         pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
         glds16(src + pi * 1024 + lane16, dst + pi * 1024);
       }
@@ -998,7 +1028,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
   // position pos) holds channel slot pos ^ ((q >> PIXROW_L) & (SLOTS - 1)); stride 2 keeps even / odd columns in halves ----
   const int npiece = a.patch_bytes >> 10;
   auto dma_piece = [&](int tp, int chunk, int buf, int k) {
-    const int piece = (wave - NWR) + k * NWP;
+    const int piece = (wave - LW0 - NWR) + k * NWP;
     if (piece >= npiece) return;  // wave-uniform; patch waves wait with vmcnt(0), nothing counts their instructions
 #ifdef KO_PATCH
     return;
@@ -1020,20 +1050,50 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
   };
 
   // ---- prologue: first stage's patch, first PFD ring steps ----
-  if (!ring_wave) {
+  if constexpr (NWL > 0) {
+    for (int c = tid; c < CT; c += NT + 64 * NWL) {
+      ((float *)(ring + NBUF * WCHUNK))[c] = a.bias[ctile * CT + c];
+      if constexpr (SC) ((float *)(ring + NBUF * WCHUNK))[CT + c] = a.bias_sc[ctile * CT + c];
+    }
+  }
+  if (patch_wave) {
 #pragma unroll
     for (int k = 0; k < UNP; ++k) dma_piece(t, 0, 0, k);
   }
 #pragma unroll
   for (int d = 0; d < PFD; ++d) issue_ring();
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   int cur = 0, slot_rd = 0;
   uint4v resv[WCB][WPB][2], resl[1][1][2];
+  float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
+  auto load_biases = [&]() {
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+        if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+      }
+  };
+  // loader-wave variant: the biases of this (persistent) workgroup's cout tile sit in LDS behind the ring, written before
+  // the prologue barrier, and are read in the epilogue (32 VGPRs less than keeping them in registers)
+  const float *bias_lds = (const float *)(ring + NBUF * WCHUNK);
+  int opix[WPB], gidx[WPB];
+  auto load_residual = [&]() {
+    if (!a.res) return;
+#pragma unroll
+    for (int i = 0; i < WCB; ++i)
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) {
+        const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
+      }
+  };
   for (; t < ntiles; t += tstep) {
     int tx, ty, n0;
     tile_decode(t, tx, ty, n0);
-    int opix[WPB], gidx[WPB];
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
       const int lxj = lmap[j] & 31, lyj = (lmap[j] >> 5) & 31, lsl = (lmap[j] >> 10) & 255, lsj = (lmap[j] >> 18) & 4095;
@@ -1067,19 +1127,20 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
         issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
-        if (!ring_wave && has_next) {
+        if (patch_wave && has_next) {
 #pragma unroll
           for (int k = 0; k < PPS; ++k)
             if (g * PPS + k < UNP) dma_piece(tn, cn, cur ^ 1, g * PPS + k);
         }
+        if (NWL && !loader && chunk == NCHUNK - 1 && g == 0) load_residual();  // a whole chunk ahead of the epilogue
         // ---- MFMAs of this step: fragment reads two items ahead, counted waits ----
-        {
+        if (!loader) {
           constexpr int NITEM = GT * KS, NR = WCB + WPB;
           const uint32_t wb = lds0 + 2 * a.patch_bytes + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
-          half8 fa[3][WCB], fb[3][WPB];
+          half8 fa[FD + 1][WCB], fb[FD + 1][WPB];
           uint32_t rowa[WPB], hs[WPB];
           auto issue = [&](auto ic) {
-            constexpr int item = decltype(ic)::value, sl = item % 3, tt = item / KS, ks = item % KS;
+            constexpr int item = decltype(ic)::value, sl = item % (FD + 1), tt = item / KS, ks = item % KS;
             if constexpr (ks == 0) {
               const int tp = g * GT + tt;
               const int te = (SC && tp == TAPS) ? 4 : tp;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
@@ -1106,11 +1167,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
 #endif
           };
           issue(std::integral_constant<int, 0>{});
-          if constexpr (NITEM > 1) issue(std::integral_constant<int, 1>{});
+          if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
           static_for<NITEM>([&](auto ic) {
-            constexpr int item = decltype(ic)::value, sl = item % 3;
-            if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
-            constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
+            constexpr int item = decltype(ic)::value, sl = item % (FD + 1);
+            if constexpr (item + FD < NITEM) issue(std::integral_constant<int, item + FD>{});
+            constexpr int younger = (NITEM - 1 - item < FD ? NITEM - 1 - item : FD) * NR;
             lds_wait<younger>();
 #pragma unroll
             for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
@@ -1140,7 +1201,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
           if (PFD >= 3 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPWR) : "memory");
           else if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (g == NG - 1) {
+        } else if (patch_wave && g == NG - 1) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #ifndef KO_BARRIER
@@ -1161,26 +1222,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_ring_dma_ke
     }
     continue;
 #endif
-    // ---- epilogue (biases and residual are read here: the other workgroup of the CU covers the latency) ----
-    float4v bq[WCB][4], bsq[SC ? WCB : 1][4];
-#pragma unroll
-    for (int i = 0; i < WCB; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bq[i][q] = *(const float4v *)(a.bias + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-        if constexpr (SC) bsq[i][q] = *(const float4v *)(a.bias_sc + ctile * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-      }
-    if (a.res) {
-#pragma unroll
-      for (int i = 0; i < WCB; ++i)
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) {
-          const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * COUT + ctile * CT + (wc * WCB + i) * 32 + 8 * h;
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)a.res + o + 16 * qq);
-        }
+    // ---- epilogue.  Without loader waves the biases and the residual are read here (the CU's other workgroup covers the
+    // latency); with them the biases were loaded once per kernel and the residual a chunk ago ----
+    if (loader) continue;
+    if constexpr (NWL == 0) {
+      load_biases();
+      load_residual();
     }
-    conv_epilogue<COUT, CT, WCB, WPB, SC, NSPLIT>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+    conv_epilogue<COUT, CT, WCB, WPB, SC, NSPLIT>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl, NWL ? bias_lds : nullptr);
   }
 }
 
@@ -1299,24 +1348,28 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
 
     // ---- conv1 + bn1 + relu on tile + 1-pixel halo (18 x 34 = 612 pixels = 20 blocks) -> T (fp16, LDS) ----
     load_weights(W1);
-    for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
-      const int m = pb * 32 + p;
-      const bool ok = m < T_H * T_W;
-      const int mm = ok ? m : 0;
-      const int y1 = mm / T_W, x1 = mm - y1 * T_W;
+    // Blocks 0..17: one T row each, columns 0..31 (32 consecutive patch pixels: conflict-free fragment reads; a block that
+    // wrapped over the row end would shift part of its lanes by XW - T_W pixels).  Blocks 18, 19: columns 32, 33 of all rows.
+    for (int pb = wave; pb < T_H + 2; pb += NW) {
+      const int m = (pb - T_H) * 32 + p;  // blocks 18, 19: index into the 2 x 18 leftover pixels
+      const bool ok = pb < T_H || m < 2 * T_H;
+      const int y1 = pb < T_H ? pb : (ok ? m >> 1 : 0), x1 = pb < T_H ? p : 32 + (m & 1);
       const float16v acc = conv_block(X, (y1 * XW + x1) * PS + h * 16, XW);
       // positions outside the picture are conv2's zero padding, not conv1 of padded input
       const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;
       const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;
-      if (ok) {
-        char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
+      half4 o[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 o;
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] + b1r[q][e], 0.f) : (_Float16)0.f;
-          *(half4 *)(dst + 16 * q) = o;
-        }
+        for (int e = 0; e < 4; ++e) o[q][e] = inside ? (_Float16)fmaxf(acc[4 * q + e] + b1r[q][e], 0.f) : (_Float16)0.f;
+      // 16-byte stores (pair16: lanes 0-31 take channels 16qq..+7, lanes 32-63 the next 8): ds_write_b128 at an 80-byte
+      // pixel pitch is conflict-free, the four ds_write_b64 it replaces were 2-way conflicted
+      char *dst = T + (y1 * T_W + x1) * PS + 16 * h;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const uint4v w = pair16(o[2 * qq], o[2 * qq + 1]);  // every lane takes part in the swap
+        if (ok) *(uint4v *)(dst + 32 * qq) = w;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1326,13 +1379,16 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
     for (int pb = wave; pb < TH * TW / 32; pb += NW) {
       const int y = pb, x = p;  // one tile row per block (TW = 32)
       const float16v acc = conv_block(T, (y * T_W + x) * PS + h * 16, T_W);
-      const char *rsrc = X + ((y + 2) * XW + x + 2) * PS + 8 * h;
+      const char *rsrc = X + ((y + 2) * XW + x + 2) * PS + 16 * h;  // residual = centre of the input patch, 16-byte reads
       half4 hq[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const half4 r = *(const half4 *)(rsrc + 16 * q);
+      for (int qq = 0; qq < 2; ++qq) {
+        half4 r[2];
+        unpair16(*(const uint4v *)(rsrc + 32 * qq), r[0], r[1]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b2r[q][e] + (float)r[e], 0.f);
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hq[2 * qq + k][e] = (_Float16)fmaxf(acc[8 * qq + 4 * k + e] + b2r[2 * qq + k][e] + (float)r[k][e], 0.f);
       }
       const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * C + (size_t)(tx * TW + x) * C + 8 * h;
 #pragma unroll
@@ -1630,6 +1686,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ks], b, acc, 0, 0, 0);
       }
       const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;  // outside: conv2's zero padding
+      // (16-byte paired stores and row-wise blocks as in block32_kernel were measured slower here: the kernel sits at 256 VGPRs)
       if (ok) {
         char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
 #pragma unroll
@@ -1765,20 +1822,21 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   return hipGetLastError();
 }
 
-template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW>
+template <int CIN, int COUT, int STRIDE, bool SC, int KC, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UNP, int MINW, int NWL, int FD>
 static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t st) {
-  auto kern = conv_ring_dma_kernel<CIN, COUT, STRIDE, SC, KC, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UNP, MINW>;
+  auto kern = conv_ring_dma_kernel<CIN, COUT, STRIDE, SC, KC, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UNP, MINW, NWL, FD>;
   constexpr int CBT = WCB * WAVES_C, NW = WAVES_C * WAVES_P;
-  const int lds = 2 * a.patch_bytes + RB * GT * (KC / 16) * CBT * 1024;
+  constexpr int NWP = NWL ? NWL - NWL / 2 : NW - NW / 2;
+  const int lds = 2 * a.patch_bytes + RB * GT * (KC / 16) * CBT * 1024 + (NWL ? 32 * CBT * 4 * (SC ? 2 : 1) : 0);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     configured = true;
   }
-  if (lds > 160 * 1024 || (a.patch_bytes >> 10) > UNP * (NW - NW / 2)) return hipErrorInvalidValue;
+  if (lds > 160 * 1024 || (a.patch_bytes >> 10) > UNP * NWP) return hipErrorInvalidValue;
   dim3 grid(grid_x, COUT / (32 * CBT));
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (NW + NWL)), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1878,6 +1936,12 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_BIG_DMA_UNP   // patch pieces per patch wave and stage (upper bound, checked at launch)
 #define CFG_BIG_DMA_UNP 7
 #endif
+#ifndef CFG_BIG_DMA_NWL   // extra loader waves (0: the compute waves issue the LDS-DMA themselves)
+#define CFG_BIG_DMA_NWL 0
+#endif
+#ifndef CFG_BIG_DMA_FD    // fragment prefetch distance (items)
+#define CFG_BIG_DMA_FD 2
+#endif
 #ifndef CFG_BIG_DMA_MINW  // min waves per SIMD (VGPR cap)
 #define CFG_BIG_DMA_MINW 4
 #endif
@@ -1931,9 +1995,9 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
 #if CFG_BIG_DMA
   if (dma && !exact && cin == 128 && cout == 128 && stride == 1)
-    return launch_ring_dma_t<128, 128, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_BIG_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW>(a, grid_x, st);
+    return launch_ring_dma_t<128, 128, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_BIG_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW, CFG_BIG_DMA_NWL, CFG_BIG_DMA_FD>(a, grid_x, st);
   if (dma && !exact && cin == 256 && cout == 256 && stride == 1)
-    return launch_ring_dma_t<256, 256, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_256_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW>(a, grid_x, st);
+    return launch_ring_dma_t<256, 256, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_256_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW, CFG_BIG_DMA_NWL, CFG_BIG_DMA_FD>(a, grid_x, st);
 #endif
 #if CFG_64_DMA
   if (dma && !exact && cin == 64 && cout == 64 && stride == 1)

@@ -10,12 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {
-    "ko_all": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1'],
-    "ko_all_reads": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_READS=1'],
-    "ko_all_epi": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_EPI=1'],
-    "ko_all_reads_epi": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_RING=1', 'KO_PATCH=1', 'KO_BARRIER=1', 'KO_READS=1', 'KO_EPI=1'],
-    "ko_reads_only": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_READS=1'],
-    "ko_epi_only": ['CFG_BIG_DMA=1', 'CFG_BIG_DMA_WP=8', 'KO_EPI=1'],
+    "base": [],
+    "rows": ["CFG_STEMB_ROWS=1"],
+    "pair": ["CFG_STEMB_PAIR=1"],
+    "base_b": [],
 }
 
 
