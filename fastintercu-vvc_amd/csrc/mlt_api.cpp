@@ -248,7 +248,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
   const bool persistent = (pc.gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
   // ring-DMA: one 16-wave or two 8-wave workgroups per CU, counted over all cout tiles
-  const int cap = dma == 2 ? wg_cap * (pc.mt_dma >= 256 ? 1 : 2) / (pc.cout / pc.ct) : wg_cap;
+  const int cap = dma == 2 ? wg_cap * ((pc.mt_dma >= 256 || pc.stride == 2) ? 1 : 2) / (pc.cout / pc.ct) : wg_cap;  // stride 2: LDS fits one
   const int grid_x = (persistent && a.ntiles > cap) ? cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "conv3x3_s%d_%dto%d_h%d%s", pc.stride, pc.cin, pc.cout, hout, pc.has_sc ? "+sc" : "");

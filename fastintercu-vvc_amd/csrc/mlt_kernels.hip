@@ -1951,6 +1951,21 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_256_DMA_RB  // ring depth, 256@8 (its 4-sample patch buffers leave room for 3 slots at most)
 #define CFG_256_DMA_RB (CFG_BIG_DMA_RB > 3 ? 3 : CFG_BIG_DMA_RB)
 #endif
+#ifndef CFG_S2A_DMA      // 64->128 stride-2 (+shortcut) on conv_ring_dma_kernel: 0.51 -> 0.47 ms (one workgroup per CU, ring depth 3)
+#define CFG_S2A_DMA 1
+#endif
+#ifndef CFG_S2B_DMA      // 128->256 stride-2 (+shortcut): measured 2 % slower than the register-staged kernel, off
+#define CFG_S2B_DMA 0
+#endif
+#ifndef CFG_S2_DMA_RB
+#define CFG_S2_DMA_RB 3
+#endif
+#ifndef CFG_S2_DMA_NWL
+#define CFG_S2_DMA_NWL 0
+#endif
+#ifndef CFG_S2_DMA_MINW
+#define CFG_S2_DMA_MINW 2
+#endif
 // dma (fast arithmetic only): 0 none, 1 resident-weights DMA mode of conv_mfma_kernel, 2 conv_ring_dma_kernel with
 // its own pixel tiling {wpb, wp}_dma (the cout tiling, KC and GT -- i.e. the weight packing -- are shared)
 struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_dma, wp_dma; };
@@ -1959,9 +1974,9 @@ static const CfgRow kCfg[] = {
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
     {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
     {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA},
-    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
+    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP},
     {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
-    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}},
+    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP},
     {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
@@ -1998,6 +2013,14 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, 
     return launch_ring_dma_t<128, 128, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_BIG_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW, CFG_BIG_DMA_NWL, CFG_BIG_DMA_FD>(a, grid_x, st);
   if (dma && !exact && cin == 256 && cout == 256 && stride == 1)
     return launch_ring_dma_t<256, 256, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_256_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW, CFG_BIG_DMA_NWL, CFG_BIG_DMA_FD>(a, grid_x, st);
+#endif
+#if CFG_S2A_DMA
+  if (dma && !exact && cin == 64 && cout == 128 && stride == 2)
+    return launch_ring_dma_t<64, 128, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
+#endif
+#if CFG_S2B_DMA
+  if (dma && !exact && cin == 128 && cout == 256 && stride == 2)
+    return launch_ring_dma_t<128, 256, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
 #endif
 #if CFG_64_DMA
   if (dma && !exact && cin == 64 && cout == 64 && stride == 1)

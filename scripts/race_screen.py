@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Race screen for the hand-synchronised kernels (LDS-DMA visibility, counted vmcnt / lgkmcnt waits): the same batch is
+run many times through the device entry point and every run must be bit-identical to the first, for several batch
+sizes (different tile counts / tails).  GPU box only.  usage: race_screen.py [repeats]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import mltcnn_pkg
+
+pkg = mltcnn_pkg.load()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda", 0)
+bad = 0
+for size, flags, batches in ((128, 0, (4096, 1000, 37, 1)), (64, pkg.capi.FLAG_FAST_SMALL, (4096, 333)), (32, 0, (2048,))):
+    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 5)
+    m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, max_batch=max(batches), flags=flags)
+    nl = m.num_logits(size)
+    for B in batches:
+        org, pred = pkg.synth.make_patches_bulk(size, B, 77)
+        poc, qp = pkg.synth.make_scalars(B, 77)
+        d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+        split = torch.zeros(B, dtype=torch.int32, device=dev)
+        lg = torch.zeros((B, nl), dtype=torch.float32, device=dev)
+        ref = None
+        for r in range(reps):
+            lg.fill_(float("nan"))
+            m.predict_batch_device(B, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), split.data_ptr(), lg.data_ptr())
+            m.synchronize()
+            cur = (lg.cpu().numpy().copy(), split.cpu().numpy().copy())
+            if ref is None:
+                ref = cur
+                assert np.isfinite(cur[0]).all()
+            elif not (np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1])):
+                bad += 1
+                print(f"MISMATCH size {size} batch {B} run {r}: {np.abs(ref[0] - cur[0]).max()}")
+        print(f"size {size} batch {B}: {reps} runs identical" if bad == 0 else f"size {size} batch {B}: mismatches so far {bad}")
+    m.close()
+sys.exit(1 if bad else 0)

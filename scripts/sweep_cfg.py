@@ -9,10 +9,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
-VARIANTS = {
+VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "rows": ["CFG_STEMB_ROWS=1"],
-    "pair": ["CFG_STEMB_PAIR=1"],
+    "s2a_regstage": ["CFG_S2A_DMA=0"],
+    "big_ringdma_16w": ["CFG_BIG_DMA=1", "CFG_BIG_DMA_WP=8"],
     "base_b": [],
 }
 

@@ -176,6 +176,26 @@ def test_decision_guard_replaces_near_ties_with_exact_results(gpu):
         m.close()
 
 
+def test_repeated_runs_bit_identical_128(gpu):
+    """The conv kernels synchronise by hand (LDS-DMA landing published by counted vmcnt + barrier, fragment reads behind
+    counted lgkmcnt): a missing wait shows up as run-to-run differences.  Ragged batch => partial tiles / tail workgroups."""
+    pkg = gpu
+    size, n = 128, 301
+    blob = pkg.weights.synthetic_blob(0, 12)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 9)
+    poc, qp = pkg.synth.make_scalars(n, 9)
+    m = _ctx(pkg, size, blob)
+    s0, l0 = m.predict_batch(org, pred, poc, qp)
+    assert np.isfinite(l0).all()
+    for _ in range(6):
+        s1, l1 = m.predict_batch(org, pred, poc, qp)
+        assert np.array_equal(l0, l1) and np.array_equal(s0, s1)
+    # and the first CUs do not depend on how many follow (different tile counts / persistent-grid shapes)
+    s2, l2 = m.predict_batch(org[:40], pred[:40], poc[:40], qp[:40])
+    assert np.array_equal(l2, l0[:40]) and np.array_equal(s2, s0[:40])
+    m.close()
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)
