@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time the synchronous one-CU-per-call path (mlt_predict)")
+    ap.add_argument("--host-staged", action="store_true",
+                    help="also time mlt_predict_batch from pinned HOST buffers (PCIe-inclusive rate; never `value`)")
     args = ap.parse_args()
 
     import numpy as np
@@ -132,6 +134,20 @@ def main():
             lat.append(time.perf_counter() - c0)
         batch1_us = float(np.median(lat[10:]) * 1e6)
 
+    # ---- PCIe-inclusive rate: the same batch from pinned host memory through mlt_predict_batch (H2D of both planes,
+    # kernels, D2H of split + logits), informational (SURVEY.md §8d "device-resident vs staged") ----
+    staged = None
+    if args.host_staged:
+        ho = torch.from_numpy(org).pin_memory().numpy()
+        hp = torch.from_numpy(pred).pin_memory().numpy()
+        m.predict_batch(ho, hp, poc, qp)
+        ts = []
+        for _ in range(5):
+            c0 = time.perf_counter()
+            m.predict_batch(ho, hp, poc, qp)
+            ts.append(time.perf_counter() - c0)
+        staged = B / float(np.median(ts))
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     # ---- roofline of the dominant kernel (largest total device time) ----
@@ -195,6 +211,7 @@ def main():
                     "mfma_frac_whole_net": round(value / world * FLOP_PER_CU / 1e12 / MFMA_PEAK_TFLOPS, 4),
                     "hbm_layerwise_roofline_frac": round(value / world * LAYERWISE_BYTES_PER_CU / 1e9 / HBM_PEAK_GBS, 4),
                     "batch1_sync_call_us": None if batch1_us is None else round(batch1_us, 1),
+                    "host_staged_cu_per_s": None if staged is None else round(staged, 1),
                     "kernels": kernels},
     }
     print(json.dumps(out))

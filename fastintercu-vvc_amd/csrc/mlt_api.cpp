@@ -68,6 +68,12 @@ struct mlt_ctx {
   char *ws = nullptr;
   size_t ws_bytes = 0;
   char *zero_page = nullptr;  // 64 KiB of zeros: padding source of the LDS-DMA patch staging
+  // mlt_predict_batch: second stream + events for the H2D / compute overlap, CUs per staged sub-chunk (MLT_STAGE_CHUNK)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  int stage_chunk = 512;  // measured on 4096 x 128x128 from pinned memory: 512 -> 526 k, 1024 -> 498 k, 2048 -> 426 k CU/s
+  char *h_res = nullptr;  // pinned result staging (split + logits) for the two sets
+  size_t h_res_bytes = 0;
   SingleCu single[4];
   // staging for the host-pointer entry points
   char *stage = nullptr;
@@ -518,6 +524,8 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
   if (cfg->guard_margin > 0.f) ctx->guard_margin = cfg->guard_margin;
   if (const char *e = std::getenv("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
+  if (const char *e = std::getenv("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
+  if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_init_error = "hipStreamCreate failed"; delete ctx; return MLT_ERR_HIP; }
   if (hipMalloc((void **)&ctx->zero_page, 65536) != hipSuccess || hipMemset(ctx->zero_page, 0, 65536) != hipSuccess) {
     g_init_error = "zero page allocation failed";
@@ -571,6 +579,9 @@ void mlt_shutdown(mlt_ctx *ctx) {
   }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (int b = 0; b < 2; ++b) { if (ctx->ev_h2d[b]) (void)hipEventDestroy(ctx->ev_h2d[b]); if (ctx->ev_done[b]) (void)hipEventDestroy(ctx->ev_done[b]); }
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -629,30 +640,90 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   const int nl = st->model.n_logits;
   const size_t cs = (size_t)size * size;
-  const int cap = n < ctx->chunk ? n : ctx->chunk;
+  // Host batches are pipelined in sub-chunks through TWO staging sets: the H2D copy of sub-chunk k+1 (copy stream) runs
+  // under the kernels of sub-chunk k (compute stream).  256 MiB of planes per 4096 CUs take about as long over PCIe as the
+  // network does, so the overlap is worth ~1.5x end to end when the caller's buffers are pinned (mlt_alloc_pinned).
+  const int cap = n < ctx->stage_chunk ? n : ctx->stage_chunk;
   const size_t plane = (cs * 2 * cap + 255) / 256 * 256;
   const size_t small = ((size_t)cap * 4 + 255) / 256 * 256;
   const size_t lgb = ((size_t)cap * nl * 4 + 255) / 256 * 256;
-  if ((rc = ensure_stage(ctx, 2 * plane + 3 * small + lgb))) return rc;
-  int16_t *d_org = (int16_t *)ctx->stage, *d_pred = (int16_t *)(ctx->stage + plane);
-  int32_t *d_poc = (int32_t *)(ctx->stage + 2 * plane), *d_qp = (int32_t *)(ctx->stage + 2 * plane + small);
-  int32_t *d_split = (int32_t *)(ctx->stage + 2 * plane + 2 * small);
-  float *d_lg = (float *)(ctx->stage + 2 * plane + 3 * small);
+  const size_t setbytes = 2 * plane + 3 * small + lgb;
+  const int nset = n > cap ? 2 : 1;
+  if ((rc = ensure_stage(ctx, nset * setbytes))) return rc;
+  if (nset == 2 && !ctx->copy_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[b], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming));
+    }
+  }
+  int16_t *d_org, *d_pred;
+  int32_t *d_poc, *d_qp, *d_split;
+  float *d_lg;
+  auto use_set = [&](int b) {
+    char *base = ctx->stage + (size_t)b * setbytes;
+    d_org = (int16_t *)base; d_pred = (int16_t *)(base + plane);
+    d_poc = (int32_t *)(base + 2 * plane); d_qp = (int32_t *)(base + 2 * plane + small);
+    d_split = (int32_t *)(base + 2 * plane + 2 * small);
+    d_lg = (float *)(base + 2 * plane + 3 * small);
+  };
   const bool guard = st->guard && !st->exact;
   std::vector<float> own_lg;  // the guard selects on host logits; keep a private copy if the caller wants none
   float *const user_logits = logits;
   if (guard && !logits) { own_lg.resize((size_t)n * nl); logits = own_lg.data(); }
-  for (int i0 = 0; i0 < n; i0 += cap) {
-    const int c = n - i0 < cap ? n - i0 : cap;
-    HIP_TRY(ctx, hipMemcpyAsync(d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = run_network(ctx, *st, st->model, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(split_mode + i0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (logits) HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)i0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // Results come back through pinned buffers owned by the context: a D2H into the caller's (usually pageable) arrays
+  // would block the host until the kernels are done and serialise the next sub-chunk's H2D behind them.
+  const size_t hres_set = (size_t)cap * 4 + (size_t)cap * nl * 4;
+  if (nset == 2 && ctx->h_res_bytes < 2 * hres_set) {
+    if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    ctx->h_res = nullptr; ctx->h_res_bytes = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_res, 2 * hres_set, hipHostMallocDefault));
+    ctx->h_res_bytes = 2 * hres_set;
   }
+  int pend_i0[2] = {-1, -1}, pend_c[2] = {0, 0};
+  auto flush = [&](int b) -> int {  // sub-chunk in set b has completed: hand its results to the caller
+    if (pend_i0[b] < 0) return MLT_OK;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done[b]));
+    const char *hb = ctx->h_res + (size_t)b * hres_set;
+    std::memcpy(split_mode + pend_i0[b], hb, (size_t)pend_c[b] * 4);
+    if (logits) std::memcpy(logits + (size_t)pend_i0[b] * nl, hb + (size_t)cap * 4, (size_t)pend_c[b] * nl * 4);
+    pend_i0[b] = -1;
+    return MLT_OK;
+  };
+  int k = 0;
+  for (int i0 = 0; i0 < n; i0 += cap, ++k) {
+    const int c = n - i0 < cap ? n - i0 : cap;
+    const int b = nset == 2 ? (k & 1) : 0;
+    use_set(b);
+    hipStream_t cps = nset == 2 ? ctx->copy_stream : ctx->stream;
+    if (nset == 2 && (rc = flush(b))) return rc;  // set b: sub-chunk k-2 fully drained (host-side wait)
+    HIP_TRY(ctx, hipMemcpyAsync(d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
+    if (nset == 2) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[b], cps));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[b], 0));
+    }
+    if ((rc = run_network(ctx, *st, st->model, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
+    if (nset == 2) {
+      char *hb = ctx->h_res + (size_t)b * hres_set;
+      HIP_TRY(ctx, hipMemcpyAsync(hb, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (logits) HIP_TRY(ctx, hipMemcpyAsync(hb + (size_t)cap * 4, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_done[b], ctx->stream));
+      pend_i0[b] = i0; pend_c[b] = c;
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(split_mode + i0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (logits) HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)i0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  if (nset == 2) {
+    if ((rc = flush(k & 1))) return rc;        // older of the two pending sub-chunks first
+    if ((rc = flush((k & 1) ^ 1))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  use_set(0);
   if (guard) {  // re-evaluate near-tie CUs with the exact arithmetic
     const float *lg = logits;
     std::vector<int> idx;

@@ -89,8 +89,9 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride,
                 int size, int32_t poc, int32_t qp, int32_t *split_mode, float *logits_opt);
 
-/* n CUs from HOST memory (pinned memory from mlt_alloc_pinned avoids a staging copy).
- * org / pred: dense [n][size][size] int16.  Synchronous.  logits may be NULL. */
+/* n CUs from HOST memory.  org / pred: dense [n][size][size] int16.  Synchronous.  logits may be NULL.
+ * Batches larger than one staging sub-chunk (512 CUs, MLT_STAGE_CHUNK) are pipelined: the H2D copy of the next
+ * sub-chunk overlaps the kernels of the current one -- effective only when org / pred are pinned (mlt_alloc_pinned). */
 int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred,
                       const int32_t *poc, const int32_t *qp, int32_t *split_mode, float *logits);
 

@@ -196,6 +196,24 @@ def test_repeated_runs_bit_identical_128(gpu):
     m.close()
 
 
+def test_pipelined_host_batch_equals_single_pass(gpu):
+    """mlt_predict_batch pipelines host batches in 512-CU sub-chunks over two staging sets (H2D under compute); the result
+    must be bit-identical to evaluating the same CUs in separate small calls, ragged last sub-chunk included."""
+    pkg = gpu
+    size, n = 64, 512 * 3 + 77
+    blob = pkg.weights.synthetic_blob(1, 4)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 21)
+    poc, qp = pkg.synth.make_scalars(n, 21)
+    m = _ctx(pkg, size, blob)
+    s_all, l_all = m.predict_batch(org, pred, poc, qp)
+    s_only, _ = m.predict_batch(org, pred, poc, qp, want_logits=False)
+    assert np.array_equal(s_only, s_all)
+    for lo, hi in ((0, 300), (300, 512), (512, 1024), (1536, n)):
+        s, l = m.predict_batch(org[lo:hi], pred[lo:hi], poc[lo:hi], qp[lo:hi])
+        assert np.array_equal(l, l_all[lo:hi]) and np.array_equal(s, s_all[lo:hi])
+    m.close()
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)
