@@ -219,8 +219,13 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
-  const int dma = pc.exact ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
-  const int MT = dma == 2 ? pc.mt_dma : pc.mt;
+  // Small batches (the encoder's one-CU-per-call use): the throughput tiling would put a whole layer on 1-4 workgroups
+  // that stream all its weights through their LDS one after the other.  The latency variants cut the couts into 32-channel
+  // tiles (4x more workgroups, 4x fewer weight bytes each) on the same packed weights.
+  static const long lat_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
+  const bool lat = !pc.exact && pc.lat && hout >= 8 && (long)n * hout * hout <= lat_px;
+  const int dma = (pc.exact || lat) ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
+  const int MT = lat ? 128 : dma == 2 ? pc.mt_dma : pc.mt;
   const int nsplit = pc.exact ? 2 : 1;
   int tw = hout < 32 ? hout : 32;
   int th = MT / tw < hout ? MT / tw : hout;
@@ -266,7 +271,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, dma != 0, a, grid_x, extra_lds, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;

@@ -32,7 +32,7 @@ struct ConvArgs {
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };
 
-struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma; };  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
+struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma, lat; };  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
 
 struct Stem5Args {
   const int16_t *org, *pred;   // Pel planes
@@ -78,7 +78,8 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
+enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2 };  // kernel variant of a layer shape
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
 hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);

@@ -304,7 +304,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
 //          pixel are XOR-swizzled with the pixel index (each lane picks the GLOBAL slot it fetches) which makes the
 //          fragment ds_read_b128 conflict-free for 16 consecutive patch pixels, as the padding does in the other modes.
 //          Picture-border / batch-tail items are fetched from a zero page (a.zero).
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA>
+//   CBP    > 0: the weights are packed for cout tiles of CBP 32-channel blocks but this instantiation's tile has fewer
+//          (CBT divides CBP): blockIdx.y counts the narrower tiles and the weight steps gather their 1 KiB pieces with
+//          the packed stride.  Used by the small-batch ("latency") variants, which spread the couts of a layer over
+//          4x more workgroups than the throughput tiling without a second packed copy of the weights.
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0>
 // MINW = minimum waves per SIMD (second __launch_bounds__ argument, caps the VGPR allocation); 1 = unconstrained
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
@@ -461,9 +465,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
     lmap[j] = x | (y << 5) | (((mm & ((1 << (tw_l + th_l)) - 1)) >> 5) << 10) | (sm << 18) | ((ok ? 1 : 0) << 30);
   }
 
-  const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
+  constexpr int CBK = CBP ? CBP : CBT;  // 32-channel blocks per PACKED cout tile
+  static_assert(CBK % CBT == 0, "packed cout tile is a multiple of this kernel's tile");
+  const char *wsrc = (const char *)a.w + (size_t)(ctile / (CBK / CBT)) * NCHUNK * TT * (KS * CBK * 1024) + (size_t)(ctile % (CBK / CBT)) * CBT * 1024;
   auto issue_step = [&](int chunk, int g, int buf) {
-    const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBT * 1024);
+    const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBK * 1024);
     char *dst = wring + buf * NSPLIT * WCHUNK;
     // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
     // its own re-copies the last piece (same bytes to the same place: benign)
@@ -473,7 +479,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
         int pi = wave + k * NW;
         pi = pi < NPIECE ? pi : NPIECE - 1;
-        glds16(src + sp * w_lo + pi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
+        const int spi = CBK == CBT ? pi : (pi / CBT) * CBK + pi % CBT;  // piece index in the packed (wider) tile
+        glds16(src + sp * w_lo + spi * 1024 + lane * 16, dst + sp * WCHUNK + pi * 1024);
       }
   };
   // weights that fit one step and one chunk stay resident in LDS for the life of the (persistent) workgroup
@@ -1762,32 +1769,45 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
 // Every class of a head runs the identical operation sequence, so identical rows tie exactly.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
-  __shared__ float feat[256 + 2];
+  __shared__ float feat[MLT_MAX_HEADS_K][256 + 2];
   __shared__ float lg[MLT_MAX_LOGITS_K];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float fpoc = (float)a.poc[n], fqp = (float)a.qp[n];  // EncCu.cpp:881-882 (int -> float, exact)
-  int lo = 0;
+  // GAP features of ALL heads first (one barrier instead of two per head: this kernel is pure latency, and it is a
+  // visible share of the one-CU-per-call path).  The partial sums are added in slot order as before -- same rounding --
+  // but eight loads are in flight at a time instead of one.
   for (int hd = 0; hd < a.n_heads; ++hd) {
-    const int C = a.c[hd], K = a.classes[hd], slots = a.slots[hd];
+    const int C = a.c[hd], slots = a.slots[hd];
     if (tid < C) {
       const float *g = a.gap[hd] + (size_t)n * slots * C + tid;
       float s = 0.f;
-      for (int i = 0; i < slots; ++i) s += g[(size_t)i * C];
-      feat[tid] = s / (float)a.hw[hd];
+      for (int i = 0; i < slots; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + u < slots ? g[(size_t)(i + u) * C] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i + u < slots) s += v[u];
+      }
+      feat[hd][tid] = s / (float)a.hw[hd];
     }
-    if (tid == 0) { feat[C] = fpoc; feat[C + 1] = fqp; }
-    __syncthreads();
+    if (tid == 0) { feat[hd][C] = fpoc; feat[hd][C + 1] = fqp; }
+  }
+  __syncthreads();
+  int lo = 0;
+  for (int hd = 0; hd < a.n_heads; ++hd) {
+    const int C = a.c[hd], K = a.classes[hd];
     for (int k = wave; k < K; k += 4) {
       const float *w = a.w[hd] + (size_t)k * (C + 2);
       float s = 0.f;
-      for (int i = lane; i < C + 2; i += 64) s += w[i] * feat[i];
+      for (int i = lane; i < C + 2; i += 64) s += w[i] * feat[hd][i];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
       if (lane == 0) lg[lo + k] = s + a.b[hd][k];
     }
     lo += K;
-    __syncthreads();
   }
+  __syncthreads();
   if (tid < lo && a.logits) a.logits[(size_t)n * lo + tid] = lg[tid];
   if (tid == 0) {
     int off = 0;
@@ -1802,9 +1822,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA, CBP>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
@@ -1968,16 +1988,25 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #endif
 // dma (fast arithmetic only): 0 none, 1 resident-weights DMA mode of conv_mfma_kernel, 2 conv_ring_dma_kernel with
 // its own pixel tiling {wpb, wp}_dma (the cout tiling, KC and GT -- i.e. the weight packing -- are shared)
-struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_dma, wp_dma; };
+#ifndef CFG_LAT        // small-batch ("latency") variants of the >= 128-channel layers: 32-cout tiles, 4 waves, 128 pixels
+#define CFG_LAT 1
+#endif
+#ifndef CFG_LAT_GT     // taps per weight step, stride-1 latency variants (9 taps: 1, 3 or 9); batch-1 sweep: 9 is fastest
+#define CFG_LAT_GT 9
+#endif
+#ifndef CFG_LAT_GT2    // stride-2 (+shortcut, 10 weight taps: 1, 2, 5 or 10)
+#define CFG_LAT_GT2 10
+#endif
+struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_dma, wp_dma, lat; };  // lat: has a latency variant (fast arithmetic)
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
     {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
-    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA},
-    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP},
-    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
-    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP},
-    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP},
+    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA, 0, 0, CFG_LAT},
+    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
+    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
+    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
     {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
@@ -1992,6 +2021,8 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
       out->dma = exact ? 0 : r.dma;
       out->mt = 32 * r.wpb * r.wp;
       out->mt_dma = r.dma == 2 ? 32 * r.wpb_dma * r.wp_dma : out->mt;
+      // the variants assume weights packed for 128-cout tiles (64 for the 64-channel layer)
+      out->lat = (!exact && r.lat && r.wcb * r.wc == (r.cout == 64 ? 2 : 4)) ? 1 : 0;
       out->gt = r.gt[exact ? 1 : 0];
       return true;
     }
@@ -2007,7 +2038,18 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   }
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, bool dma, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+  const bool dma = variant == MLT_CONV_DMA;
+#if CFG_LAT
+  if (variant == MLT_CONV_LATENCY && !exact) {  // 32 couts x 128 pixels per 4-wave workgroup, weights packed for CBP = 4
+    if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 64, 1, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 128 && stride == 1) return launch_conv_t<128, 128, 1, 9, false, 64, 1, 1, 1, 1, 4, CFG_LAT_GT, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 256 && cout == 256 && stride == 1) return launch_conv_t<256, 256, 1, 9, false, 64, 1, 1, 1, 1, 4, CFG_LAT_GT, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4>(a, grid_x, extra_lds, st);
+    return hipErrorInvalidValue;
+  }
+#endif
 #if CFG_BIG_DMA
   if (dma && !exact && cin == 128 && cout == 128 && stride == 1)
     return launch_ring_dma_t<128, 128, 1, false, 64, CFG_BIG_WCB, CFG_BIG_DMA_WPB, CFG_BIG_WC, CFG_BIG_DMA_WP, CFG_BIG_GT, CFG_BIG_DMA_RB, CFG_BIG_DMA_UNP, CFG_BIG_DMA_MINW, CFG_BIG_DMA_NWL, CFG_BIG_DMA_FD>(a, grid_x, st);
