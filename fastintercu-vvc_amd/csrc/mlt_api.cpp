@@ -392,7 +392,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
     io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
     static const bool no_fuse0 = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-    const bool fused_b0 = s == 0 && !m.exact && ho >= 32 && !no_fuse0;
+    // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
+    const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
+    const bool fused_b0 = s == 0 && !m.exact && ho >= 32 && !no_fuse0 && quad_ok;
     if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;
       if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2]))) return rc;

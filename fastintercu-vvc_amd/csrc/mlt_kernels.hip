@@ -25,6 +25,9 @@
 #ifndef CFG_ASM_PIPE  // 1: fragment ds_reads issued from inline asm, 2 items ahead, with counted lgkmcnt waits (fast arithmetic)
 #define CFG_ASM_PIPE 1
 #endif
+#ifndef CFG_S2_BIAS_EARLY  // ... of the stride-2 ring kernels (two bias sets = 64 VGPRs)
+#define CFG_S2_BIAS_EARLY 1
+#endif
 #ifndef CFG_BIAS_EARLY  // 1: bias loads before the MFMA phase (latency hidden, +16..32 VGPRs); 0: at the epilogue
 #define CFG_BIAS_EARLY 1
 #endif
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
     };
     // early (latency hidden under the MFMA phase, +16..32 live VGPRs) where registers are not the occupancy limiter;
     // the stride-1 ring kernels load them at the epilogue (measured: 128@16 0.41 vs 0.48 ms)
-    constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || SC);
+    constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || (SC && CFG_S2_BIAS_EARLY));
     if constexpr (BIAS_EARLY) load_biases();
 
     float16v acc[WCB][WPB];
@@ -1591,7 +1594,8 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
   constexpr int RH = 2 * T_H + 3, RW = 2 * T_W + 3;         // raw patch 39 x 71
   constexpr int HW = (RW + 1) / 2, RP = 2 * HW;             // parity-split columns, row pitch 72
   constexpr int RAWBYTES = (RH * RP * 4 + 15) / 16 * 16, TBYTES = T_H * T_W * PS;
-  constexpr int NT = 512, NW = 8, UR = 6;                   // 39*71 = 2769 raw pixels <= 6 * 512
+  constexpr int NT = 512, NW = 8;
+  constexpr int QW = (RW + 3) / 4, UR = (RH * QW + NT - 1) / NT;  // raw rows are fetched as 18 quads of 4 pixels: 702 items, 2 per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t *raw = (uint32_t *)smem;
   char *T = smem + RAWBYTES, *W2 = T + TBYTES;
@@ -1615,16 +1619,20 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
   for (int k = 0; k < 5; ++k) am[k] = *(const half8 *)((const char *)a.w + k * 1024 + lane * 16);
 #pragma unroll
   for (int k = 0; k < 2; ++k) as[k] = *(const half8 *)((const char *)a.w + (5 + k) * 1024 + lane * 16);
-  float4v b1r[4], bsr[4], b2r[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    b1r[q] = *(const float4v *)(a.bias + 4 * h + 8 * q);
-    bsr[q] = *(const float4v *)(a.bias_sc + 4 * h + 8 * q);
-    b2r[q] = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
+  // biases in LDS (this kernel is register-bound: 48 VGPRs of biases meant spills inside the block loops):
+  // BL[0..31] = bias of conv1 (bn1), BL[32..63] = bias of conv2 (bn2) + bias of the shortcut, which are only ever added together
+  float *BL = (float *)(W2 + 18 * 1024);
+  if (tid < 32) {
+    BL[tid] = a.bias[tid];
+    BL[32 + tid] = a.bias2[tid] + a.bias_sc[tid];
   }
   // ---- raw patch: issue (global -> registers) / commit (registers -> LDS) ----
-  int16_t vo[UR], vp[UR];
-  int rdst[UR];  // dword index in `raw`, bit 30: zero-fill, -1: none
+  // One item = 4 horizontally adjacent pixels of both planes (two 8-byte loads).  The patch starts at column 64*tx - 4 and the
+  // planes are dense 2H x 2H int16 with 8-byte aligned rows (host guarantees it), so quads are aligned and lie entirely
+  // inside or outside the picture.  (Pixel-wise 2-byte loads made ISSUING the next tile's loads 42 % of the tile time.)
+  typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+  uint2v vo[UR], vp[UR];
+  int rdst[UR];  // dword index in `raw` of the quad's first even pixel, bit 30: zero-fill, -1: none
   auto issue_raw = [&](int t) {
     int tx, ty, n;
     tile_decode(t, tx, ty, n);
@@ -1632,34 +1640,52 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const int it = tid + u * NT;
-      const int ry = it / RW, rx = it - ry * RW;
-      const int iy = iy0 + ry, ix = ix0 + rx;
-      const bool in_items = it < RH * RW;
+      const int ry = it / QW, qx = it - ry * QW;
+      const int iy = iy0 + ry, ix = ix0 + 4 * qx;
+      const bool in_items = it < RH * QW;
       const bool live = in_items && iy >= 0 && iy < S && ix >= 0 && ix < S;
-      rdst[u] = in_items ? (ry * RP + (rx & 1) * HW + (rx >> 1)) | (live ? 0 : 1 << 30) : -1;
-      const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + (tid & (S - 1));
-      const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + (tid & (S - 1));
-      vo[u] = a.org[oo];
-      vp[u] = a.pred[po];
+      rdst[u] = in_items ? (ry * RP + 2 * qx) | (live ? 0 : 1 << 30) : -1;
+      const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + ((tid * 4) & (S - 1));
+      const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + ((tid * 4) & (S - 1));
+      vo[u] = *(const uint2v *)(a.org + oo);
+      vp[u] = *(const uint2v *)(a.pred + po);
     }
   };
   auto commit_raw = [&]() {
 #pragma unroll
-    for (int u = 0; u < UR; ++u)
-      if (rdst[u] >= 0) raw[rdst[u] & ~(1 << 30)] = (rdst[u] & (1 << 30)) ? 0u : prep_pair(vo[u], vp[u]);
+    for (int u = 0; u < UR; ++u) {
+      if (rdst[u] < 0) continue;
+      const bool zf = rdst[u] & (1 << 30);
+      const int d = rdst[u] & ~(1 << 30);
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int16_t o = (int16_t)(vo[u][j >> 1] >> (16 * (j & 1))), q = (int16_t)(vp[u][j >> 1] >> (16 * (j & 1)));
+        w[j] = zf ? 0u : prep_pair(o, q);
+      }
+      uint2v ev, od;  // parity-split columns: pixels 0, 2 -> even half, 1, 3 -> odd half (8-byte stores)
+      ev[0] = w[0]; ev[1] = w[2]; od[0] = w[1]; od[1] = w[3];
+      *(uint2v *)(raw + d) = ev;
+      *(uint2v *)(raw + d + HW) = od;
+    }
   };
   auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
   auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
 
   int t = blockIdx.x;
   if (t < ntiles) issue_raw(t);
+  PH_DECL;
   for (; t < ntiles; t += gridDim.x) {
     int tx, ty, n;
     tile_decode(t, tx, ty, n);
+    PH_MARK(7);
     commit_raw();
+    PH_MARK(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PH_MARK(1);
     const int t_next = t + gridDim.x;
     if (t_next < ntiles) issue_raw(t_next);
+    PH_MARK(2);
 
     // ---- phase 1: t on tile + halo (18 x 34 = 612 pixels = 20 blocks), composed 5x5 stride-2 conv -> T (fp16, LDS) ----
     for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
@@ -1699,13 +1725,16 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           half4 ov;
+          const float4v b1q = *(const float4v *)(BL + 4 * h + 8 * q);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] * a.acc_scale + b1r[q][e], 0.f) : (_Float16)0.f;
+          for (int e = 0; e < 4; ++e) ov[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] * a.acc_scale + b1q[e], 0.f) : (_Float16)0.f;
           *(half4 *)(dst + 16 * q) = ov;
         }
       }
     }
+    PH_MARK(3);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PH_MARK(4);
 
     // ---- phase 2: conv2(t) from T + shortcut (composed 3x3 stride-2 conv of the raw planes, fp32) + relu -> b0 ----
     for (int pb = wave; pb < TH * TW / 32; pb += NW) {
@@ -1750,16 +1779,20 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
       }
       half4 hq[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q) {
+        const float4v bq = *(const float4v *)(BL + 32 + 4 * h + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + b2r[q][e] + (accs[4 * q + e] * a.acc_scale + bsr[q][e]), 0.f);
+        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + (accs[4 * q + e] * a.acc_scale + bq[e]), 0.f);
+      }
       const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * 32 + (size_t)(tx * TW + x) * 32 + 8 * h;
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
     }
+    PH_MARK(5);
     if (t_next < ntiles) __builtin_amdgcn_s_barrier();  // the next commit overwrites raw, the next phase 1 overwrites T
+    PH_MARK(6);
   }
+  PH_FLUSH(14);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2100,7 +2133,7 @@ hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) 
 }
 
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st) {
-  constexpr int lds = (39 * 72 * 4 + 15) / 16 * 16 + 18 * 34 * 80 + 18 * 1024;
+  constexpr int lds = (39 * 72 * 4 + 15) / 16 * 16 + 18 * 34 * 80 + 18 * 1024 + 256;  // raw + T + conv2 weights + biases
   hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(512), lds, st, a);  // 78 KiB: two workgroups per CU
   return hipGetLastError();
 }

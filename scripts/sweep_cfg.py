@@ -11,10 +11,10 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "s2_rb4": ["CFG_S2_DMA_RB=4"],
-    "s2b_rb3": ["CFG_S2B_DMA=1"],
-    "s2b_rb4": ["CFG_S2B_DMA=1", "CFG_S2_DMA_RB=4"],
-    "s2_rb2": ["CFG_S2_DMA_RB=2"],
+    "s2_minw4": ["CFG_S2_MINW=4"],
+    "s2_biaslate": ["CFG_S2_BIAS_EARLY=0"],
+    "s2_biaslate_minw4": ["CFG_S2_BIAS_EARLY=0", "CFG_S2_MINW=4"],
+    "s2_biaslate_minw3": ["CFG_S2_BIAS_EARLY=0", "CFG_S2_MINW=3"],
     "base_b": [],
 }
 
