@@ -1348,13 +1348,18 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
 
   int t = blockIdx.x;
   if (t < ntiles) issue_patch(t);
+  PH_DECL;
   for (; t < ntiles; t += gridDim.x) {
     int tx, ty, n;
     tile_decode(t, tx, ty, n);
+    PH_MARK(7);
     commit_patch();  // waits for exactly the prefetched loads (the resident weights' DMA is older, hence landed too)
+    PH_MARK(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PH_MARK(1);
     const int t_next = t + gridDim.x;
     if (t_next < ntiles) issue_patch(t_next);
+    PH_MARK(2);
 
     // ---- conv1 + bn1 + relu on tile + 1-pixel halo (18 x 34 = 612 pixels = 20 blocks) -> T (fp16, LDS) ----
     load_weights(W1);
@@ -1382,7 +1387,9 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
         if (ok) *(uint4v *)(dst + 32 * qq) = w;
       }
     }
+    PH_MARK(3);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PH_MARK(4);
 
     // ---- conv2 + bn2 + residual (input patch centre) + relu on the 16 x 32 tile (16 blocks) -> HBM ----
     load_weights(W2);
@@ -1405,8 +1412,11 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
       for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
     }
     // the next commit overwrites X, the next conv1 overwrites T
+    PH_MARK(5);
     if (t_next < ntiles) __builtin_amdgcn_s_barrier();
+    PH_MARK(6);
   }
+  PH_FLUSH(13);
 }
 
 // ---------------------------------------------------------------------------------------------

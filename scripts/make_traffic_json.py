@@ -17,7 +17,7 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        m = re.search(r"conv_mfma_kernel<(\d+), (\d+), (\d)", k)
+        m = re.search(r"conv_(?:mfma|ring_dma)_kernel<(\d+), (\d+), (\d)", k)
         if m:
             cin, cout, st = map(int, m.groups())
             name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")

@@ -34,6 +34,8 @@ for kid in range(16):
     tot = sum(row)
     if not tot:
         continue
+    if kid == 13:
+        print("block32_kernel: phases = commit patch | barrier | issue next patch | conv1 -> T | barrier | conv2 + residual + store | barrier | tile decode")
     if kid == 14:
         print("stem_block_kernel: phases = commit raw | barrier | issue next raw | phase 1 (composed 5x5 -> T) | barrier | phase 2 (conv2 + shortcut + store) | barrier | tile decode")
     print(f"kernel id {kid} (cin={32 * (kid & 7)}, stride={2 if kid & 8 else 1}): total {tot / 1e6:.1f} Mcycles (wave 0, all WGs, all launches)")
