@@ -58,7 +58,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    pkg.build.build_lib()
+    if rank == 0:
+        pkg.build.build_lib()  # no-op when the in-tree library is current; never let N ranks race hipcc on one output file
+    if dist is not None:
+        dist.barrier()
 
     size, B = args.size, args.batch
     arch = pkg.synth.arch_for_size(size)

@@ -28,6 +28,9 @@
 #ifndef CFG_S2_BIAS_EARLY  // ... of the stride-2 ring kernels (two bias sets = 64 VGPRs)
 #define CFG_S2_BIAS_EARLY 1
 #endif
+#ifndef CFG_DMA_SPREAD  // DMA mode: issue one patch piece every N fragment items of the MFMA loop (0: all before the loop)
+#define CFG_DMA_SPREAD 5
+#endif
 #ifndef CFG_BIAS_EARLY  // 1: bias loads before the MFMA phase (latency hidden, +16..32 VGPRs); 0: at the epilogue
 #define CFG_BIAS_EARLY 1
 #endif
@@ -504,14 +507,13 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 
   // ---- DMA staging: UN LDS-DMA instructions per wave move one tile's patch; LDS position of item it is it * 16 bytes,
   // item = (patch pixel q, position pos) holds channel slot pos ^ ((q >> PIXROW_L) & (SLOTS - 1)) ----
-  auto dma_patch = [&](int t, int buf) {
+  auto dma_piece = [&](int t, int buf, int k) {  // k-th of this wave's UN pieces of tile t
     int tx, ty, n0;
     tile_decode(t, tx, ty, n0);
     const int iy0 = (ty << th_l) - PAD, ix0 = (tx << tw_l) - PAD;
     const int npiece = a.patch_bytes >> 10, npix = (1 << spw_l) * PH * PW;
     char *dst = smem + buf * a.patch_bytes;
-#pragma unroll
-    for (int k = 0; k < UN; ++k) {
+    {
       int piece = wave + k * NW;
       piece = piece < npiece ? piece : npiece - 1;  // every wave issues exactly UN instructions (counted vmcnt); extras re-copy the last KiB
       const int it = piece * 64 + lane;
@@ -525,6 +527,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
                              : (const char *)a.zero + ((((int)blockIdx.x * NT + tid) * 16) & 0xFFF0);  // spread over the zero page: no hot line
       glds16(src, dst + piece * 1024);
     }
+  };
+  auto dma_patch = [&](int t, int buf) {
+#pragma unroll
+    for (int k = 0; k < UN; ++k) dma_piece(t, buf, k);
   };
 
   int t = blockIdx.x;
@@ -635,7 +641,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       // next tile's patch into the other buffer (all waves passed the previous tile's closing barrier, so nobody reads it);
       // the last tile re-fetches itself so that the number of outstanding operations does not depend on the path
       PH_MARK(0);
-      dma_patch(t_next < ntiles ? t_next : t, cur ^ 1);
+      const int t_dma = t_next < ntiles ? t_next : t;
+      if constexpr (!(ASM_PIPE && CFG_DMA_SPREAD)) dma_patch(t_dma, cur ^ 1);
       PH_MARK(1);
       const char *pb = smem + cur * a.patch_bytes;
       if constexpr (ASM_PIPE) {
@@ -665,6 +672,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
         issue(std::integral_constant<int, 1>{});
         static_for<NITEM>([&](auto ic) {
           constexpr int item = decltype(ic)::value, sl = item % 3;
+          // the next tile's patch pieces are issued one at a time under the first MFMAs instead of as a burst in front of
+          // them (all eight waves issuing 6 KiB each at once kept the wave at the issue for 18 % of the tile time)
+          if constexpr (CFG_DMA_SPREAD && item % CFG_DMA_SPREAD == 0 && item / CFG_DMA_SPREAD < UN) dma_piece(t_dma, cur ^ 1, item / CFG_DMA_SPREAD);
           if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
           constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
           lds_wait<younger>();
@@ -1598,7 +1608,10 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
 // and read back by the two-kernel form) never exist.  conv2's weights are resident in LDS (and in registers during the
 // phase), the composed first-layer weights live in registers; persistent workgroups prefetch the next raw patch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) {
+#ifndef CFG_STEMB_MINW
+#define CFG_STEMB_MINW 1
+#endif
+__global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const StemBlockArgs a) {
   constexpr int TH = 16, TW = 32, PS = 80;
   constexpr int T_H = TH + 2, T_W = TW + 2;                 // t region: tile + 1-pixel halo
   constexpr int RH = 2 * T_H + 3, RW = 2 * T_W + 3;         // raw patch 39 x 71

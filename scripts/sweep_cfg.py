@@ -10,12 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
-    "base": [],
-    "s2_minw4": ["CFG_S2_MINW=4"],
-    "s2_biaslate": ["CFG_S2_BIAS_EARLY=0"],
-    "s2_biaslate_minw4": ["CFG_S2_BIAS_EARLY=0", "CFG_S2_MINW=4"],
-    "s2_biaslate_minw3": ["CFG_S2_BIAS_EARLY=0", "CFG_S2_MINW=3"],
-    "base_b": [],
+    "burst": ["CFG_DMA_SPREAD=0"],
+    "spread3": [],
+    "spread2": ["CFG_DMA_SPREAD=2"],
+    "spread5": ["CFG_DMA_SPREAD=5"],
+    "burst_b": ["CFG_DMA_SPREAD=0"],
+    "spread3_b": [],
 }
 
 
