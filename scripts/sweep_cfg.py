@@ -10,12 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
-    "burst": ["CFG_DMA_SPREAD=0"],
-    "spread3": [],
-    "spread2": ["CFG_DMA_SPREAD=2"],
-    "spread5": ["CFG_DMA_SPREAD=5"],
-    "burst_b": ["CFG_DMA_SPREAD=0"],
-    "spread3_b": [],
+    "base": [],
+    "s2a_regstage": ["CFG_S2A_DMA=0"],
+    "dma64_burst": ["CFG_DMA_SPREAD=0"],
+    "base_b": [],
 }
 
 
