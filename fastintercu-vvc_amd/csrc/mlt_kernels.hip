@@ -1949,8 +1949,11 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_BIG_WPB  // 128@16, 256@8 stride-1
 #define CFG_BIG_WPB 1
 #endif
-#ifndef CFG_BIG_WP
-#define CFG_BIG_WP 4
+#ifndef CFG_BIG_WP   // 8: one 16-wave workgroup per CU on 256-pixel tiles (with 3 taps per weight step: 128@16 0.405 -> 0.389 ms,
+#define CFG_BIG_WP 8 // 256@8 0.340 -> 0.317 ms vs two 8-wave workgroups on 128-pixel tiles with 1 tap per step)
+#endif
+#ifndef CFG_BIG_WP_EXACT  // ... exact arithmetic (small-CU models, maps of 1..16 pixels): 128-pixel tiles, 8 waves
+#define CFG_BIG_WP_EXACT 4
 #endif
 #ifndef CFG_BIG_WCB
 #define CFG_BIG_WCB 2
@@ -1979,8 +1982,8 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_64_GT      // taps per weight step, 64@32 stride-1 (9 = all weights resident in LDS)
 #define CFG_64_GT 9
 #endif
-#ifndef CFG_BIG_GT     // 128@16 / 256@8 stride-1
-#define CFG_BIG_GT 1
+#ifndef CFG_BIG_GT     // 128@16 / 256@8 stride-1: taps per weight step (48 KiB steps, 6 barriers per 64-channel chunk instead of 18)
+#define CFG_BIG_GT 3
 #endif
 #ifndef CFG_S1_MINW   // min waves / SIMD of the 64..256-channel stride-1 kernels (VGPR cap)
 #define CFG_S1_MINW 1
@@ -2075,7 +2078,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
       out->kc = r.kc[exact ? 1 : 0];
       out->ct = 32 * r.wcb * r.wc;
       out->dma = exact ? 0 : r.dma;
-      out->mt = 32 * r.wpb * r.wp;
+      out->mt = 32 * r.wpb * ((exact && r.cin >= 128 && r.stride == 1) ? CFG_BIG_WP_EXACT : r.wp);
       out->mt_dma = r.dma == 2 ? 32 * r.wpb_dma * r.wp_dma : out->mt;
       // the variants assume weights packed for 128-cout tiles (64 for the 64-channel layer)
       out->lat = (!exact && r.lat && r.wcb * r.wc == (r.cout == 64 ? 2 : 4)) ? 1 : 0;
@@ -2087,11 +2090,14 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 
 // RBF / RBE: weight-ring depth (fast / exact).  Must mirror kCfg.
 // UNF / UNE: patch items per lane prefetched in registers (fast / exact), sized for the 128x128 model's tiles
-#define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)                                    \
+// WPF / WPE: waves along pixels, fast / exact (the exact kernels serve the small-CU models, whose maps are tiny)
+#define CONV_CASE2(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WPF, WPE, GTF, GTE, RBF, RBE, UNF, UNE, MWF)                              \
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
-    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WP, GTF, RBF, UNF, MWF, false>(a, grid_x, extra_lds, st); \
-    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WP, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st);           \
+    if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WPF, GTF, RBF, UNF, MWF, false>(a, grid_x, extra_lds, st); \
+    return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st);          \
   }
+#define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF) \
+  CONV_CASE2(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
@@ -2128,9 +2134,9 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
   CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
   CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_GT, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
+  CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
   CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_GT, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
+  CONV_CASE2(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2, 5, 3, 1)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2, 3, 2, 1)
   CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2, 5, 3, 1)

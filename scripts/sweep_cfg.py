@@ -11,8 +11,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "s2a_regstage": ["CFG_S2A_DMA=0"],
-    "dma64_burst": ["CFG_DMA_SPREAD=0"],
+    "big_2wg_gt1": ["CFG_BIG_WP=4", "CFG_BIG_GT=1"],
+    "un_more": ["CFG_BIG_UN=1"],
     "base_b": [],
 }
 
