@@ -2033,11 +2033,17 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_S2A_DMA      // 64->128 stride-2 (+shortcut) on conv_ring_dma_kernel: 0.51 -> 0.47 ms (one workgroup per CU, ring depth 3)
 #define CFG_S2A_DMA 1
 #endif
-#ifndef CFG_S2B_DMA      // 128->256 stride-2 (+shortcut): measured 2 % slower than the register-staged kernel, off
-#define CFG_S2B_DMA 0
+#ifndef CFG_S2B_DMA      // 128->256 stride-2 (+shortcut): with 5 taps per weight step 0.41 -> 0.345 ms (register-staged kernel at 5 taps: 0.365)
+#define CFG_S2B_DMA 1
 #endif
 #ifndef CFG_S2_DMA_RB
-#define CFG_S2_DMA_RB 3
+#define CFG_S2_DMA_RB 2
+#endif
+#ifndef CFG_S2A_GT       // taps per weight step of the 64->128 ring-DMA kernel (10 weight taps: 1, 2, 5); 5 with ring depth 2: 0.46 -> 0.41 ms
+#define CFG_S2A_GT 5
+#endif
+#ifndef CFG_S2B_GT       // ... of the 128->256 kernel (either variant)
+#define CFG_S2B_GT 5
 #endif
 #ifndef CFG_S2_DMA_NWL
 #define CFG_S2_DMA_NWL 0
@@ -2064,7 +2070,7 @@ static const CfgRow kCfg[] = {
     {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA, 0, 0, CFG_LAT},
     {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
     {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
-    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
+    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {CFG_S2B_GT, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
     {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
     // CU model (planes 32/64/96/128/256)
     {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
@@ -2120,11 +2126,11 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
 #endif
 #if CFG_S2A_DMA
   if (dma && !exact && cin == 64 && cout == 128 && stride == 2)
-    return launch_ring_dma_t<64, 128, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
+    return launch_ring_dma_t<64, 128, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2A_GT, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
 #endif
 #if CFG_S2B_DMA
   if (dma && !exact && cin == 128 && cout == 256 && stride == 2)
-    return launch_ring_dma_t<128, 256, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
+    return launch_ring_dma_t<128, 256, 2, true, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, CFG_S2_DMA_RB, 20, CFG_S2_DMA_MINW, CFG_S2_DMA_NWL, 2>(a, grid_x, st);
 #endif
 #if CFG_64_DMA
   if (dma && !exact && cin == 64 && cout == 64 && stride == 1)
@@ -2135,7 +2141,7 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
   CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
   CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
-  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, 1, 2, 2, 5, 3, CFG_S2_MINW)
   CONV_CASE2(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2, 5, 3, 1)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2, 3, 2, 1)

@@ -11,8 +11,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "big_2wg_gt1": ["CFG_BIG_WP=4", "CFG_BIG_GT=1"],
-    "un_more": ["CFG_BIG_UN=1"],
+    "s2_fd1": ["CFG_S2_DMA_FD=1"],
+    "s2_ld4": ["CFG_S2_DMA_NWL=4"],
     "base_b": [],
 }
 
