@@ -1952,6 +1952,12 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_BIG_WP   // 8: one 16-wave workgroup per CU on 256-pixel tiles (with 3 taps per weight step: 128@16 0.405 -> 0.389 ms,
 #define CFG_BIG_WP 8 // 256@8 0.340 -> 0.317 ms vs two 8-wave workgroups on 128-pixel tiles with 1 tap per step)
 #endif
+#ifndef CFG_GTE_S1   // exact arithmetic: taps per weight step, stride-1 (9 taps: 1, 3) / stride-2 + shortcut (10: 1, 2, 5)
+#define CFG_GTE_S1 1
+#endif
+#ifndef CFG_GTE_S2
+#define CFG_GTE_S2 1
+#endif
 #ifndef CFG_BIG_WP_EXACT  // ... exact arithmetic (small-CU models, maps of 1..16 pixels): 128-pixel tiles, 8 waves
 #define CFG_BIG_WP_EXACT 4
 #endif
@@ -2066,16 +2072,16 @@ struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
-    {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, 1}},
-    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, 1}, CFG_64_DMA, 0, 0, CFG_LAT},
-    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, 1}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
-    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
-    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {CFG_S2B_GT, 1}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
-    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, 1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
+    {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, CFG_GTE_S2}},
+    {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, CFG_GTE_S1}, CFG_64_DMA, 0, 0, CFG_LAT},
+    {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, CFG_GTE_S2}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
+    {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, CFG_GTE_S1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
+    {128, 256, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {CFG_S2B_GT, CFG_GTE_S2}, CFG_S2B_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
+    {256, 256, 1, {64, 32}, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, CFG_GTE_S1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
     // CU model (planes 32/64/96/128/256)
-    {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, 1}},
-    {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, 1}},
-    {96, 128, 2, {32, 32}, 2, 2, 2, 2, {2, 1}},
+    {64, 96, 2, {32, 32}, 3, 1, 1, 4, {1, CFG_GTE_S2}},
+    {96, 96, 1, {32, 32}, 3, 1, 1, 4, {3, CFG_GTE_S1}},
+    {96, 128, 2, {32, 32}, 2, 2, 2, 2, {2, CFG_GTE_S2}},
 };
 
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
@@ -2137,15 +2143,15 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
     return launch_conv_t<64, 64, 1, 9, false, 64, 1, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 9, 1, CFG_64_DMA_UN, CFG_S1_MINW, true>(a, grid_x, extra_lds, st);
 #endif
   CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
-  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, 1, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
-  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, 1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
-  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
-  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, 1, 2, 2, 5, 3, CFG_S2_MINW)
-  CONV_CASE2(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, 1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
-  CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, 1, 2, 2, 5, 3, 1)
-  CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, 1, 2, 2, 3, 2, 1)
-  CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, 1, 2, 2, 5, 3, 1)
+  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
+  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, CFG_GTE_S1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
+  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_GTE_S2, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, CFG_GTE_S1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
+  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, CFG_GTE_S2, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE2(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, CFG_GTE_S1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
+  CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, CFG_GTE_S2, 2, 2, 5, 3, 1)
+  CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, CFG_GTE_S1, 2, 2, 3, 2, 1)
+  CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, CFG_GTE_S2, 2, 2, 5, 3, 1)
   return hipErrorInvalidValue;
 }
 
