@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Bring-up aid (GPU box): run one small batch with MLT_DEBUG_DUMP_DIR set and compare every dumped
 activation tensor against a torch-CPU emulation of the SAME pipeline (fp32 math on the folded fp32
-weights), printing max abs error per layer.  Not part of the product or the tests."""
+weights), printing max abs error per layer.  Runs the UNFUSED layer0 path (MLT_NO_BLOCK_FUSION) so that every
+conv output exists in HBM.  Not part of the product or the tests."""
 import os
 import sys
 import tempfile
@@ -20,6 +21,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     dump = tempfile.mkdtemp(prefix="mltdump_")
     os.environ["MLT_DEBUG_DUMP_DIR"] = dump
+    os.environ["MLT_NO_BLOCK_FUSION"] = "1"  # one launch (and one dumped tensor) per conv: the fused layer0 kernels keep t / sc on chip
     pkg = mltcnn_pkg.load()
     pkg.build.build_lib()
     synth = pkg.synth
