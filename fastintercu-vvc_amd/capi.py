@@ -21,7 +21,7 @@ FLAG_EXACT_128 = 0x1   # 128x128 in exact (fp16 hi+lo, 3-pass) arithmetic instea
 FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
 FLAG_DECISION_GUARD = 0x4  # host entry points re-evaluate near-tie CUs with the exact arithmetic
 EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "mlt_predict_batch",
-           "mlt_predict_batch_device", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
+           "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
 
 
@@ -69,6 +69,9 @@ def load_library():
     lib.mlt_predict.argtypes = [vp, vp, i32, vp, i32, i32, C.c_int32, C.c_int32, vp, vp]
     lib.mlt_predict_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mlt_predict_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mlt_submit.argtypes = [vp, vp, i32, vp, i32, i32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+    lib.mlt_flush.argtypes = [vp, i32]
+    lib.mlt_wait.argtypes = [vp, i32, C.c_uint64, vp, vp]
     lib.mlt_synchronize.argtypes = [vp]
     lib.mlt_set_stream.argtypes = [vp, vp]
     lib.mlt_alloc_pinned.restype = vp
@@ -154,6 +157,25 @@ class MltCnn:
         self._check(self._lib.mlt_predict_batch(self._h, n, S, org.ctypes.data, pred.ctypes.data, poc.ctypes.data,
                                                 qp.ctypes.data, split.ctypes.data, logits.ctypes.data if want_logits else None))
         return split, logits
+
+    def submit(self, org: np.ndarray, pred: np.ndarray, poc: int, qp: int) -> int:
+        """Deferred single-CU prediction: stage one CU, return a ticket (see mlt_submit in include/mltcnn.h)."""
+        assert org.dtype == np.int16 and pred.dtype == np.int16 and org.ndim == 2 and org.shape == pred.shape
+        S = org.shape[0]
+        assert org.shape[1] == S and org.strides[1] == 2 and pred.strides[1] == 2
+        t = C.c_uint64(0)
+        self._check(self._lib.mlt_submit(self._h, org.ctypes.data, org.strides[0] // 2, pred.ctypes.data, pred.strides[0] // 2,
+                                         S, int(poc), int(qp), C.byref(t)))
+        return int(t.value)
+
+    def flush(self, size: int):
+        self._check(self._lib.mlt_flush(self._h, size))
+
+    def wait(self, size: int, ticket: int):
+        split = C.c_int32(-1)
+        logits = np.zeros(self.num_logits(size) or 1, np.float32)
+        self._check(self._lib.mlt_wait(self._h, size, C.c_uint64(ticket), C.byref(split), logits.ctypes.data))
+        return int(split.value), logits
 
     def predict_batch_device(self, n: int, size: int, d_org: int, d_pred: int, d_poc: int, d_qp: int, d_split: int,
                              d_logits: int | None):

@@ -54,6 +54,19 @@ struct SingleCu {
   hipStream_t stream_at_capture = nullptr;
 };
 
+// mlt_submit / mlt_flush / mlt_wait: two generations of up to MLT_DEFER_CAP CUs per size (one accumulating, one in
+// flight or finished).  Generation g uses buffer set g & 1; ticket = g * MLT_DEFER_CAP + slot.
+struct Deferred {
+  char *h_in = nullptr, *d_in = nullptr;    // [2 sets][org planes CAP][pred planes CAP][poc CAP][qp CAP]
+  char *h_out = nullptr, *d_out = nullptr;  // [2 sets][split CAP][logits CAP * nl]
+  size_t in_set = 0, out_set = 0, plane = 0;
+  uint64_t gen = 0;                         // generation being filled
+  int n = 0;                                // CUs submitted into it
+  int n_launched[2] = {0, 0};               // CUs of the generation occupying each set (0: never launched)
+  uint64_t gen_of_set[2] = {~0ull, ~0ull};
+  hipEvent_t done[2] = {nullptr, nullptr};
+};
+
 struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 
 }  // namespace
@@ -75,6 +88,7 @@ struct mlt_ctx {
   char *h_res = nullptr;  // pinned result staging (split + logits) for the two sets
   size_t h_res_bytes = 0;
   SingleCu single[4];
+  Deferred deferred[4];
   // staging for the host-pointer entry points
   char *stage = nullptr;
   size_t stage_bytes = 0;
@@ -584,6 +598,13 @@ void mlt_shutdown(mlt_ctx *ctx) {
     if (sg.h_stage) (void)hipHostFree(sg.h_stage);
     if (sg.d_stage) (void)hipFree(sg.d_stage);
   }
+  for (Deferred &df : ctx->deferred) {
+    if (df.h_in) (void)hipHostFree(df.h_in);
+    if (df.h_out) (void)hipHostFree(df.h_out);
+    if (df.d_in) (void)hipFree(df.d_in);
+    if (df.d_out) (void)hipFree(df.d_out);
+    for (int b = 0; b < 2; ++b) if (df.done[b]) (void)hipEventDestroy(df.done[b]);
+  }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -834,6 +855,104 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
   }
   *split_mode = h_sc[2];
   if (logits_opt) std::memcpy(logits_opt, h_sc + 4, (size_t)nl * 4);
+  return MLT_OK;
+}
+
+// ---- deferred single-CU prediction ----
+namespace {
+int deferred_launch(mlt_ctx *ctx, SizeState *st, Deferred &df) {  // launch the accumulating generation as one batch
+  if (df.n == 0) return MLT_OK;
+  const int size = st->size, nl = st->model.n_logits, b = (int)(df.gen & 1), n = df.n;
+  const size_t cs = (size_t)size * size;
+  char *hi = df.h_in + (size_t)b * df.in_set, *di = df.d_in + (size_t)b * df.in_set;
+  char *ho = df.h_out + (size_t)b * df.out_set, *dout = df.d_out + (size_t)b * df.out_set;
+  const size_t planes = (size_t)MLT_DEFER_CAP * df.plane;
+  // org planes, pred planes, poc, qp: four regions of the set, only the first n entries of each are live
+  HIP_TRY(ctx, hipMemcpyAsync(di, hi, (size_t)n * df.plane, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(di + planes, hi + planes, (size_t)n * df.plane, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(di + 2 * planes, hi + 2 * planes, (size_t)MLT_DEFER_CAP * 8, hipMemcpyHostToDevice, ctx->stream));
+  int32_t *d_poc = (int32_t *)(di + 2 * planes), *d_qp = d_poc + MLT_DEFER_CAP;
+  int32_t *d_split = (int32_t *)dout;
+  float *d_lg = (float *)(dout + (size_t)MLT_DEFER_CAP * 4);
+  const int rc = run_network(ctx, *st, st->model, n, (const int16_t *)di, size, (long)(df.plane / 2), (const int16_t *)(di + planes), size,
+                             (long)(df.plane / 2), d_poc, d_qp, d_split, d_lg);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ho, dout, (size_t)MLT_DEFER_CAP * 4 + (size_t)n * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(df.done[b], ctx->stream));
+  df.n_launched[b] = n;
+  df.gen_of_set[b] = df.gen;
+  ++df.gen;
+  df.n = 0;
+  (void)cs;
+  return MLT_OK;
+}
+}  // namespace
+
+int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride, int size, int32_t poc, int32_t qp,
+               mlt_ticket *ticket) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (!org || !pred || !ticket || org_stride < size || pred_stride < size) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  Deferred &df = ctx->deferred[size_index(size)];
+  const int nl = st->model.n_logits;
+  if (!df.h_in) {
+    df.plane = ((size_t)size * size * 2 + 255) / 256 * 256;
+    df.in_set = 2 * (size_t)MLT_DEFER_CAP * df.plane + (size_t)MLT_DEFER_CAP * 8;
+    df.out_set = ((size_t)MLT_DEFER_CAP * 4 * (1 + nl) + 255) / 256 * 256;
+    HIP_TRY(ctx, hipHostMalloc((void **)&df.h_in, 2 * df.in_set, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void **)&df.h_out, 2 * df.out_set, hipHostMallocDefault));
+    HIP_TRY(ctx, hipMalloc((void **)&df.d_in, 2 * df.in_set));
+    HIP_TRY(ctx, hipMalloc((void **)&df.d_out, 2 * df.out_set));
+    for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipEventCreateWithFlags(&df.done[b], hipEventDisableTiming));
+  }
+  if (df.n == MLT_DEFER_CAP && (rc = deferred_launch(ctx, st, df))) return rc;  // full: flush, start the next generation
+  const int b = (int)(df.gen & 1);
+  if (df.n == 0 && df.gen_of_set[b] != ~0ull) HIP_TRY(ctx, hipEventSynchronize(df.done[b]));  // set b's previous batch fully drained
+  char *hi = df.h_in + (size_t)b * df.in_set;
+  const size_t planes = (size_t)MLT_DEFER_CAP * df.plane;
+  char *ho = hi + (size_t)df.n * df.plane, *hp = hi + planes + (size_t)df.n * df.plane;
+  for (int y = 0; y < size; ++y) {  // the gather of EncCu.cpp:810-830
+    std::memcpy(ho + (size_t)y * size * 2, org + (size_t)y * org_stride, (size_t)size * 2);
+    std::memcpy(hp + (size_t)y * size * 2, pred + (size_t)y * pred_stride, (size_t)size * 2);
+  }
+  int32_t *h_poc = (int32_t *)(hi + 2 * planes);
+  h_poc[df.n] = poc;
+  h_poc[MLT_DEFER_CAP + df.n] = qp;
+  *ticket = df.gen * MLT_DEFER_CAP + (uint64_t)df.n;
+  ++df.n;
+  return MLT_OK;
+}
+
+int mlt_flush(mlt_ctx *ctx, int size) {
+  if (!ctx) return MLT_ERR_ARG;
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  Deferred &df = ctx->deferred[size_index(size)];
+  return df.h_in ? deferred_launch(ctx, st, df) : MLT_OK;
+}
+
+int mlt_wait(mlt_ctx *ctx, int size, mlt_ticket ticket, int32_t *split_mode, float *logits_opt) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (!split_mode) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  Deferred &df = ctx->deferred[size_index(size)];
+  const uint64_t gen = ticket / MLT_DEFER_CAP;
+  const int slot = (int)(ticket % MLT_DEFER_CAP), b = (int)(gen & 1), nl = st->model.n_logits;
+  if (!df.h_in || gen > df.gen || (gen == df.gen && slot >= df.n)) { ctx->err = "unknown ticket"; return MLT_ERR_ARG; }
+  if (gen == df.gen && (rc = deferred_launch(ctx, st, df))) return rc;  // still accumulating: launch it now
+  if (df.gen_of_set[b] != gen || slot >= df.n_launched[b]) { ctx->err = "ticket expired (two newer batches were started)"; return MLT_ERR_ARG; }
+  HIP_TRY(ctx, hipEventSynchronize(df.done[b]));
+  const char *ho = df.h_out + (size_t)b * df.out_set;
+  *split_mode = ((const int32_t *)ho)[slot];
+  if (logits_opt) std::memcpy(logits_opt, ho + (size_t)MLT_DEFER_CAP * 4 + (size_t)slot * nl * 4, (size_t)nl * 4);
   return MLT_OK;
 }
 

@@ -71,6 +71,21 @@ class SplitPredictor {
     return split;
   }
 
+  // Encoder-side batching: stage the CU now, decide later.  submitSplitMode() returns a ticket (or
+  // false on failure: treat like predictedSplitMode = -1); waitSplitMode() returns the split mode of that ticket and runs
+  // every CU staged so far for this size as ONE batch if that has not happened yet.  With k CUs whose setNewModeList
+  // call can be postponed together (e.g. the CTUs of a WPP anti-diagonal) the per-CU cost falls from ~150 us to
+  // ~150 us / k (+ ~8 us).  At most MLT_DEFER_CAP CUs per batch; a full batch is launched by the next submit.
+  bool submitSplitMode(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, mlt_ticket *ticket) {
+    return m_ctx && mlt_submit(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, ticket) == MLT_OK;
+  }
+  void flush(int cuw) { if (m_ctx) (void)mlt_flush(m_ctx, cuw); }  // start the batch early, e.g. before unrelated host work
+  int waitSplitMode(int cuw, mlt_ticket ticket, float *logitsOpt = nullptr) {
+    int32_t split = -1;
+    if (!m_ctx || mlt_wait(m_ctx, cuw, ticket, &split, logitsOpt) != MLT_OK) return -1;
+    return split;
+  }
+
  private:
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;

@@ -100,6 +100,21 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
 int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, const void *d_pred,
                              const void *d_poc, const void *d_qp, void *d_split_mode, void *d_logits);
 
+/* Deferred single-CU prediction (encoder-side batching, SURVEY.md 8f N3: "async predict + deferred setNewModeList").
+ * mlt_submit copies one CU's planes (same arguments as mlt_predict) into pinned staging and returns a ticket at once;
+ * nothing runs yet.  mlt_flush launches every CU submitted so far for that size as ONE batch and returns without
+ * waiting; mlt_wait returns a ticket's result, flushing first if its batch has not been launched.  An encoder that
+ * can postpone EncModeCtrl::setNewModeList for k independent CUs (CTUs of a wavefront, EncCu.cpp:792-800) pays one
+ * ~0.2 ms launch for all k instead of k synchronous calls.  Up to MLT_DEFER_CAP CUs per batch (a full batch is flushed
+ * by the next submit); a ticket stays valid until two further batches of its size have been started.  Results are
+ * bit-identical to mlt_predict (the decision guard is not applied on this path). */
+#define MLT_DEFER_CAP 64
+typedef uint64_t mlt_ticket;
+int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride,
+               int size, int32_t poc, int32_t qp, mlt_ticket *ticket);
+int mlt_flush(mlt_ctx *ctx, int size);
+int mlt_wait(mlt_ctx *ctx, int size, mlt_ticket ticket, int32_t *split_mode, float *logits_opt);
+
 int mlt_synchronize(mlt_ctx *ctx);
 
 /* Use an existing hipStream_t (e.g. the caller's) instead of the context's own stream; NULL switches back to a

@@ -214,6 +214,38 @@ def test_pipelined_host_batch_equals_single_pass(gpu):
     m.close()
 
 
+def test_deferred_submit_flush_wait(gpu):
+    """mlt_submit / mlt_flush / mlt_wait (encoder-side batching): tickets resolve to exactly what mlt_predict returns, in any
+    wait order, across an automatic flush of a full batch, and expired / unknown tickets are rejected."""
+    pkg = gpu
+    size = 128
+    cap = 64  # MLT_DEFER_CAP
+    blob = pkg.weights.synthetic_blob(0, 8)
+    n = cap + 9
+    org, pred = pkg.synth.make_patches_bulk(size, n, 31)
+    poc, qp = pkg.synth.make_scalars(n, 31)
+    pic = np.zeros((n, size, 200), np.int16)  # CUs taken out of wider rows: exercises the strided gather
+    pic[:, :, 40:40 + size] = org
+    m = _ctx(pkg, size, blob)
+    want = [m.predict(pic[i, :, 40:40 + size], pred[i], int(poc[i]), int(qp[i])) for i in range(n)]
+    tickets = [m.submit(pic[i, :, 40:40 + size], pred[i], int(poc[i]), int(qp[i])) for i in range(n)]  # 64 -> auto flush -> 9 pending
+    assert tickets == list(range(n))
+    for i in list(range(n - 1, cap - 1, -1)) + [5, 0, 63, 17]:  # second batch first (flushes it), then the first batch
+        s, l = m.wait(size, tickets[i])
+        assert s == want[i][0] and np.array_equal(l, want[i][1])
+    m.flush(size)  # nothing pending: no-op
+    t2 = [m.submit(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(3)]
+    m.flush(size)
+    t3 = m.submit(org[3], pred[3], int(poc[3]), int(qp[3]))
+    assert m.wait(size, t3)[0] == want[3][0]
+    assert m.wait(size, t2[1])[0] == want[1][0]  # previous generation is still readable
+    with pytest.raises(pkg.MltError):
+        m.wait(size, tickets[0])  # two newer batches were started since
+    with pytest.raises(pkg.MltError):
+        m.wait(size, t3 + 5)  # never issued
+    m.close()
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)
