@@ -246,6 +246,28 @@ def test_deferred_submit_flush_wait(gpu):
     m.close()
 
 
+def test_kernel_variant_switches_do_not_change_results(gpu):
+    """Small launches use latency variants of the >= 64-channel convs (<= 16384 output pixels per launch: 64@32 up to 16 CUs,
+    128@16 / 64->128 up to 64, 256@8 / 128->256 up to 256).  A CU's logits must be bit-identical on either side of every
+    switch point, and equal to the oracle within the tolerance."""
+    import oracle
+    pkg = gpu
+    size = 128
+    blob = pkg.weights.synthetic_blob(0, 15)
+    nmax = 258
+    org, pred = pkg.synth.make_patches_bulk(size, nmax, 41)
+    poc, qp = pkg.synth.make_scalars(nmax, 41)
+    m = _ctx(pkg, size, blob)
+    s8, l8 = m.predict_batch(org[:8], pred[:8], poc[:8], qp[:8])
+    ref, ref_split = oracle.Oracle(blob).forward(org[:8], pred[:8], poc[:8], qp[:8])
+    assert np.abs(l8 - ref).max() <= LOGIT_TOL and np.array_equal(s8, ref_split)
+    for n in (1, 16, 17, 64, 65, 256, 257, 258):
+        s, l = m.predict_batch(org[:n], pred[:n], poc[:n], qp[:n])
+        k = min(n, 8)
+        assert np.array_equal(l[:k], l8[:k]) and np.array_equal(s[:k], s8[:k]), n
+    m.close()
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)
