@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--size", type=int, default=SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags (1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16)")
     ap.add_argument("--latency", action="store_true", help="also time the synchronous one-CU-per-call path (mlt_predict)")
     ap.add_argument("--host-staged", action="store_true",
                     help="also time mlt_predict_batch from pinned HOST buffers (PCIe-inclusive rate; never `value`)")
@@ -70,7 +71,7 @@ def main():
         blob = pkg.weights.synthetic_blob(arch, 10)
     if world > 1:
         blob = pkg.shard.broadcast_blob(blob if rank == 0 else None, dist, dev)
-    m = pkg.MltCnn(device=local_rank, sizes=(size,), blobs={size: blob}, max_batch=B)
+    m = pkg.MltCnn(device=local_rank, sizes=(size,), blobs={size: blob}, max_batch=B, flags=args.flags)
 
     # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
     org, pred = pkg.synth.make_patches_bulk(size, B, 0xC0FFEE, first=rank * B)
@@ -202,7 +203,7 @@ def main():
     out = {
         "metric": "CU-inferences/sec (batch 4096, 128x128)", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if not (args.flags & 1 and size == 128) and (size == 128 or args.flags & 2) else "f16x2 (hi+lo pairs)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
                    "batch_per_gpu": B, "cu_size": size, "weights": "synthetic seed 10 (no trained checkpoint is distributed)",

@@ -11,8 +11,9 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "s2_fd1": ["CFG_S2_DMA_FD=1"],
-    "s2_ld4": ["CFG_S2_DMA_NWL=4"],
+    "big_2wg_gt1": ["CFG_BIG_WP=4", "CFG_BIG_GT=1"],
+    "s2_regstage_gt2": ["CFG_S2A_DMA=0", "CFG_S2B_DMA=0", "CFG_S2B_GT=2"],
+    "dma64_burst": ["CFG_DMA_SPREAD=0"],
     "base_b": [],
 }
 
