@@ -54,11 +54,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # one rank per GPU over RCCL.  Only for exercising this code path on a box with fewer GPUs than ranks
+        # (MLT_BENCH_OVERSUBSCRIBE=1): ranks share GPUs and the two init-time collectives go over gloo on host tensors.
+        oversub = world > torch.cuda.device_count() and os.environ.get("MLT_BENCH_OVERSUBSCRIBE") == "1"
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        dist.init_process_group(backend="gloo" if oversub else "nccl", rank=rank, world_size=world)
+    else:
+        oversub = False
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if oversub else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if oversub else dev  # where collective payloads live
     if rank == 0:
         pkg.build.build_lib()  # no-op when the in-tree library is current; never let N ranks race hipcc on one output file
     if dist is not None:
@@ -70,8 +77,8 @@ def main():
     if rank == 0:
         blob = pkg.weights.synthetic_blob(arch, 10)
     if world > 1:
-        blob = pkg.shard.broadcast_blob(blob if rank == 0 else None, dist, dev)
-    m = pkg.MltCnn(device=local_rank, sizes=(size,), blobs={size: blob}, max_batch=B, flags=args.flags)
+        blob = pkg.shard.broadcast_blob(blob if rank == 0 else None, dist, cdev)
+    m = pkg.MltCnn(device=dev_index, sizes=(size,), blobs={size: blob}, max_batch=B, flags=args.flags)
 
     # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
     org, pred = pkg.synth.make_patches_bulk(size, B, 0xC0FFEE, first=rank * B)
@@ -107,7 +114,7 @@ def main():
     prof = m.profile_read()
     m.profile_enable(False)
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 

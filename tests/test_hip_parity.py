@@ -2,6 +2,8 @@
 (b) the C oracle on seeded inputs.  Tolerance written here, from BASELINE.json's north_star:
 |dlogit| <= 1e-3 and identical split decision wherever the reference's own top-2 margin exceeds
 the tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -388,3 +390,25 @@ def test_empty_and_single_batches(gpu):
         s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
         assert s1 == s3[i] and np.array_equal(l1, l3[i])
     m.close()
+
+
+def test_bench_contract_two_ranks_on_one_gpu(gpu):
+    """bench.py under torch.distributed.run with two ranks (sharing the GPU, gloo for the init-time collectives): rank 0
+    prints exactly one JSON line carrying the contract keys, n_gpus = 2, and parity-clean results."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLT_BENCH_OVERSUBSCRIBE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["value"] > 0
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+    assert d["parity"]["max_abs_dlogit"] <= LOGIT_TOL and d["parity"]["split_identical"]
