@@ -31,6 +31,12 @@
 #ifndef CFG_DMA_SPREAD  // DMA mode: issue one patch piece every N fragment items of the MFMA loop (0: all before the loop)
 #define CFG_DMA_SPREAD 5
 #endif
+#ifndef CFG_RING_FD16  // fragment prefetch distance of the 16-wave ring kernels (1 or 2 items): same speed, 16 VGPRs fewer at 1
+#define CFG_RING_FD16 1
+#endif
+#ifndef CFG_RING_RES_EARLY
+#define CFG_RING_RES_EARLY 1
+#endif
 #ifndef CFG_BIAS_EARLY  // 1: bias loads before the MFMA phase (latency hidden, +16..32 VGPRs); 0: at the epilogue
 #define CFG_BIAS_EARLY 1
 #endif
@@ -584,6 +590,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
     // early (latency hidden under the MFMA phase, +16..32 live VGPRs) where registers are not the occupancy limiter;
     // the stride-1 ring kernels load them at the epilogue (measured: 128@16 0.41 vs 0.48 ms)
     constexpr bool BIAS_EARLY = CFG_BIAS_EARLY && (W_RESIDENT || (SC && CFG_S2_BIAS_EARLY));
+    // 16-wave stride-1 ring kernels: residual loads under the last weight step instead of in the epilogue
+    constexpr bool RES_EARLY = CFG_RING_RES_EARLY && !W_RESIDENT && NSPLIT == 1 && NG > 1 && !SC && NW == 16;
     if constexpr (BIAS_EARLY) load_biases();
 
     float16v acc[WCB][WPB];
@@ -746,6 +754,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
         char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
+        // last weight step of the tile: no ring wait follows it any more, so loads issued now fly under its MFMAs without
+        // being drained by a counted vmcnt -- the residual arrives before the epilogue needs it
+        if constexpr (RES_EARLY) {
+          if (chunk == NCHUNK - 1 && g == NG - 1) load_residual();
+        }
         if constexpr (NBUF > 1) {
           // buffer (g + PFD) % NBUF == (g - 1) % NBUF was last read in step g-1; every wave has passed that step's barrier
           if (g + PFD < NG) {
@@ -767,13 +780,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
           return STRIDE == 2 ? (dy * RPt + (dx & 1) * HALFt + (dx >> 1)) * PS : (dy * RPt + dx) * PS;
         };
         if constexpr (ASM_PIPE) {
-          // three fragment slots: the reads of items i+1 and i+2 are in flight while the MFMAs of item i run
-          constexpr int NITEM = GT * KS, NR = WCB + WPB;
+          // FDR + 1 fragment slots: the reads of the next FDR items are in flight while the MFMAs of item i run (16-wave
+          // workgroups have four waves per SIMD to cover an item and a 128-VGPR budget: one item ahead)
+          constexpr int NITEM = GT * KS, NR = WCB + WPB, FDR = (NW == 16 && CFG_RING_FD16) ? CFG_RING_FD16 : 2;
           const uint32_t wb = lds0 + (uint32_t)(wcur - smem) + (wc * WCB) * 1024 + lane16;
-          half8 fa[3][WCB], fb[3][WPB];
+          half8 fa[FDR + 1][WCB], fb[FDR + 1][WPB];
           uint32_t pbt[WPB];
           auto issue = [&](auto ic) {
-            constexpr int item = decltype(ic)::value, sl = item % 3, tt = item / KS, ks = item % KS;
+            constexpr int item = decltype(ic)::value, sl = item % (FDR + 1), tt = item / KS, ks = item % KS;
             if constexpr (ks == 0) {
               const int toff = tap_off(tt);
 #pragma unroll
@@ -786,11 +800,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
             static_for<WPB>([&](auto jj) { lds_read128<ks * 32>(fb[sl][decltype(jj)::value], pbt[decltype(jj)::value]); });
           };
           issue(std::integral_constant<int, 0>{});
-          if constexpr (NITEM > 1) issue(std::integral_constant<int, 1>{});
+          if constexpr (NITEM > 1 && FDR > 1) issue(std::integral_constant<int, 1>{});
           static_for<NITEM>([&](auto ic) {
-            constexpr int item = decltype(ic)::value, sl = item % 3;
-            if constexpr (item + 2 < NITEM) issue(std::integral_constant<int, item + 2>{});
-            constexpr int younger = (NITEM - 1 - item < 2 ? NITEM - 1 - item : 2) * NR;
+            constexpr int item = decltype(ic)::value, sl = item % (FDR + 1);
+            if constexpr (item + FDR < NITEM) issue(std::integral_constant<int, item + FDR>{});
+            constexpr int younger = (NITEM - 1 - item < FDR ? NITEM - 1 - item : FDR) * NR;
             lds_wait<younger>();
 #pragma unroll
             for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
@@ -891,7 +905,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
     (void)PF_PATCH;
   // ---- epilogue: + bias (+ residual) (ReLU) -> fp16 NHWC (8 B per register quad) and/or fp32 GAP partials ----
   if constexpr (!BIAS_EARLY) load_biases();
-  if constexpr (!W_RESIDENT) {
+  if constexpr (!W_RESIDENT && !RES_EARLY) {
     if (a.res) {  // all residual reads together (16 B per lane and quad pair), clamped address when the pixel is invalid
 #pragma unroll
       for (int i = 0; i < WCB; ++i)
