@@ -392,6 +392,39 @@ def test_empty_and_single_batches(gpu):
     m.close()
 
 
+def test_one_context_serving_all_four_cu_sizes(gpu):
+    """one context with the 128 model and the three CU-model weight sets loaded, calls of different sizes
+    interleaved (single-CU, batch and deferred entry points share workspaces, graphs and staging) == single-size contexts."""
+    pkg = gpu
+    blobs = {s: pkg.weights.synthetic_blob(pkg.synth.arch_for_size(s), 20 + s) for s in SIZES}
+    allm = pkg.MltCnn(device=0, sizes=SIZES, blobs=blobs)
+    data, want = {}, {}
+    for s in SIZES:
+        org, pred = pkg.synth.make_patches_bulk(s, 6, 50 + s)
+        poc, qp = pkg.synth.make_scalars(6, 50 + s)
+        data[s] = (org, pred, poc, qp)
+        one = _ctx(pkg, s, blobs[s])
+        want[s] = one.predict_batch(org, pred, poc, qp)
+        one.close()
+    tickets = {}
+    for rnd in range(2):
+        for s in (16, 128, 32, 64, 128, 16):
+            org, pred, poc, qp = data[s]
+            i = (rnd * 3 + s) % 6
+            sp, lg = allm.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+            assert sp == want[s][0][i] and np.array_equal(lg, want[s][1][i]), (s, i)
+            tickets.setdefault(s, []).append((i, allm.submit(org[i], pred[i], int(poc[i]), int(qp[i]))))
+        for s in SIZES:
+            org, pred, poc, qp = data[s]
+            sb, lb = allm.predict_batch(org, pred, poc, qp)
+            assert np.array_equal(sb, want[s][0]) and np.array_equal(lb, want[s][1]), s
+    for s, lst in tickets.items():
+        for i, t in lst:
+            sp, lg = allm.wait(s, t)
+            assert sp == want[s][0][i] and np.array_equal(lg, want[s][1][i]), (s, i)
+    allm.close()
+
+
 def test_bench_contract_two_ranks_on_one_gpu(gpu):
     """bench.py under torch.distributed.run with two ranks (sharing the GPU, gloo for the init-time collectives): rank 0
     prints exactly one JSON line carrying the contract keys, n_gpus = 2, and parity-clean results."""
