@@ -392,6 +392,34 @@ def test_empty_and_single_batches(gpu):
     m.close()
 
 
+@pytest.mark.parametrize("size", (128, 32))
+def test_out_of_range_pels_follow_the_reference_casts(gpu, size):
+    """Pel is int16; the reference casts to uint16, takes |o - p| on uint16 and clips the scaled value to [0, 1]
+    (EncCu.cpp:816,827,833,848-867).  Negative and > 10-bit samples must go through the same casts on the GPU (fused first
+    layer for 128, stem5 kernel for 32) as in the oracle."""
+    import oracle
+    pkg = gpu
+    n = 6
+    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 3)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 77)
+    rng = np.random.default_rng(5)
+    weird = np.array([-1, -5, -32768, 32767, 1024, 2000, 1023, 0], np.int16)
+    for a in (org, pred):
+        idx = rng.integers(0, a.size, size=a.size // 50)
+        a.reshape(-1)[idx] = rng.choice(weird, size=idx.size)
+    poc, qp = pkg.synth.make_scalars(n, 77)
+    ref, ref_split = oracle.Oracle(blob).forward(org, pred, poc, qp)
+    m = _ctx(pkg, size, blob)
+    s, l = m.predict_batch(org, pred, poc, qp)
+    assert np.abs(l - ref).max() <= LOGIT_TOL
+    hs = head_slices(pkg.synth.HEAD_CLASSES[pkg.synth.arch_for_size(size)])
+    dec = hs[2] if size == 128 else hs[0]
+    for i in range(n):
+        if decisive(ref[i], dec, 4 * LOGIT_TOL):
+            assert s[i] == ref_split[i]
+    m.close()
+
+
 def test_one_context_serving_all_four_cu_sizes(gpu):
     """one context with the 128 model and the three CU-model weight sets loaded, calls of different sizes
     interleaved (single-CU, batch and deferred entry points share workspaces, graphs and staging) == single-size contexts."""
