@@ -157,6 +157,7 @@ KIND_UNIFORM = 1     # i.i.d. uniform 10-bit org and pred
 KIND_ZERO_RESI = 2   # pred == org  (all-zero residual channel)
 KIND_SATURATED = 3   # org = 1023, pred = 0 on a checkerboard, swapped elsewhere
 KIND_FLAT = 4        # constant org, constant pred
+KIND_OUT_OF_RANGE = 5  # texture with 2 % of the samples replaced by negative / > 10-bit Pel values (uint16 cast + clip path)
 
 
 def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, first: int = 0):
@@ -189,6 +190,13 @@ def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, f
             chk = ((yy // 4 + xx // 4) & 1).astype(np.int64)
             o = chk * 1023
             p = (1 - chk) * 1023
+        elif kind == KIND_OUT_OF_RANGE:
+            o = randint(input_seed, tag + "/o", px, 0, 1023).reshape(size, size)
+            p = np.clip(o + randint(input_seed, tag + "/n", px, -40, 40).reshape(size, size), 0, 1023)
+            weird = np.array([-1, -5, -32768, 32767, 1024, 2000, 1023, 0], np.int64)
+            for arr, nm in ((o, "/wo"), (p, "/wp")):
+                pos = randint(input_seed, tag + nm + "pos", max(px // 50, 1), 0, px - 1)
+                arr.reshape(-1)[pos] = weird[randint(input_seed, tag + nm + "val", len(pos), 0, len(weird) - 1)]
         elif kind == KIND_FLAT:
             o = np.full((size, size), int(randint(input_seed, tag + "/o", 1, 0, 1023)[0]), dtype=np.int64)
             p = np.full((size, size), int(randint(input_seed, tag + "/p", 1, 0, 1023)[0]), dtype=np.int64)

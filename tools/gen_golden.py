@@ -80,6 +80,12 @@ CASES = [
     ("poc_qp_max", 10, "plain", 1006, synth.KIND_TEXTURE, 1, ([1023], [47])),
     ("poc0_features_decide", 13, "plain", 1007, synth.KIND_TEXTURE, 4, ([0, 0, 0, 0], [0, 0, 0, 0])),
     ("argmax_tie", 10, "tie", 1008, synth.KIND_TEXTURE, 2, None),
+    # further weight sets / contents (added later; the cases above are unchanged)
+    ("texture_w21", 21, "plain", 1010, synth.KIND_TEXTURE, 4, None),
+    ("texture_w22", 22, "plain", 1011, synth.KIND_TEXTURE, 4, None),
+    ("uniform_w23", 23, "plain", 1012, synth.KIND_UNIFORM, 3, None),
+    ("zero_resi_w24", 24, "plain", 1013, synth.KIND_ZERO_RESI, 2, None),
+    ("out_of_range_pels", 25, "plain", 1014, synth.KIND_OUT_OF_RANGE, 3, None),
 ]
 
 
