@@ -420,6 +420,30 @@ def test_out_of_range_pels_follow_the_reference_casts(gpu, size):
     m.close()
 
 
+def test_device_entry_point_chunk_loop(gpu, monkeypatch):
+    """mlt_predict_batch_device walks batches larger than MLT_CHUNK in chunks (workspace sized for one chunk); with a tiny
+    chunk the result must still equal the single-pass result, ragged last chunk included."""
+    import torch
+    pkg = gpu
+    size, n = 64, 250
+    blob = pkg.weights.synthetic_blob(1, 6)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 13)
+    poc, qp = pkg.synth.make_scalars(n, 13)
+    ref = _ctx(pkg, size, blob)
+    s_ref, l_ref = ref.predict_batch(org, pred, poc, qp)
+    ref.close()
+    monkeypatch.setenv("MLT_CHUNK", "96")
+    m = _ctx(pkg, size, blob, max_batch=n)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+    d_split = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    d_lg = torch.zeros((n, m.num_logits(size)), dtype=torch.float32, device=dev)
+    m.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_lg.data_ptr())
+    m.synchronize()
+    assert np.array_equal(d_split.cpu().numpy(), s_ref) and np.array_equal(d_lg.cpu().numpy(), l_ref)
+    m.close()
+
+
 def test_one_context_serving_all_four_cu_sizes(gpu):
     """one context with the 128 model and the three CU-model weight sets loaded, calls of different sizes
     interleaved (single-CU, batch and deferred entry points share workspaces, graphs and staging) == single-size contexts."""
