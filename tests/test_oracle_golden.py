@@ -70,3 +70,23 @@ def test_oracle_rejects_bad_size(pkg):
     org, pred = pkg.synth.make_patches(64, 1, 5)
     with pytest.raises(RuntimeError):
         orc.forward(org, pred, [0], [30])
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_torch_cpu_port_matches_reference_fixtures_and_c_oracle(pkg, size):
+    """oracle/torch_port.py (the CPU baseline bench.py times beside the C oracle) against the reference-generated fixtures
+    and against the C oracle on a seeded batch."""
+    import oracle
+    from oracle.torch_port import TorchPort
+    g = load_golden(size)
+    for case in g["cases"]:
+        blob, org, pred, poc, qp, exp, am = materialise(pkg, g, case)
+        lg, sp = TorchPort(blob).forward(org, pred, poc, qp, threads=4)
+        assert np.abs(lg - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max()), case["name"]
+    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 77)
+    n = 3 if size == 128 else 8
+    org, pred = pkg.synth.make_patches(size, n, 4242)
+    poc, qp = pkg.synth.make_scalars(n, 4242)
+    a, sa = oracle.Oracle(blob).forward(org, pred, poc, qp)
+    b, sb = TorchPort(blob).forward(org, pred, poc, qp, threads=4)
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
