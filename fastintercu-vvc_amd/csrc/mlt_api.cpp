@@ -256,7 +256,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   while (spw > 1 && (size_t)spw * ph * rp * PS * nsplit > 64 * 1024) spw /= 2;
   a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
-  auto magic = [](int d) { return (uint32_t)((0x100000000ull + d - 1) / d); };  // d >= 2 (ph, pw >= 3)
+  auto magic = [](int d) { return d < 2 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); };  // 0 encodes d == 1 (1x1 convs on 1x1 maps)
   a.pw_magic = magic(pw); a.ph_magic = magic(ph);
   a.patch_bytes = (int)((((size_t)spw * ph * rp * PS) + 1023) / 1024 * 1024);
   if (dma) {  // two unpadded, swizzled patch buffers; the row pitch keeps the rules above
@@ -285,7 +285,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, pc.exact, pc.taps == 1 ? MLT_CONV_CENTRE : lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
@@ -511,7 +511,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   mlt::Model m;
   std::string err;
-  if (!mlt::build_model(blob, bytes, st.exact, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  if (!mlt::build_model(blob, bytes, st.exact, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
   if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); free_model(st.model_exact); st.loaded = false; }
   st.model = std::move(m);
@@ -519,7 +519,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (rc) return rc;
   if (st.guard && !st.exact) {
     mlt::Model me;
-    if (!mlt::build_model(blob, bytes, true, me, err)) { ctx->err = "weights (exact copy): " + err; return MLT_ERR_WEIGHTS; }
+    if (!mlt::build_model(blob, bytes, true, size, me, err)) { ctx->err = "weights (exact copy): " + err; return MLT_ERR_WEIGHTS; }
     if (st.model_exact.on_device) free_model(st.model_exact);
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return rc;

@@ -78,7 +78,8 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
-enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2 };  // kernel variant of a layer shape
+enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2, MLT_CONV_CENTRE = 3 };  // kernel variant of a layer shape
+bool mlt_conv_has_centre_variant(int cin, int cout);  // 1x1 (centre-tap) instantiation for stride-1 layers on 1x1 maps
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);

@@ -109,7 +109,7 @@ __device__ __forceinline__ void stagger_start(int phases, int units) {
 }
 
 // n / d for d >= 2 with magic = ceil(2^32 / d); exact while n * d < 2^32 (patch indices are < 2^16)
-__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }  // magic 0: d == 1
 
 // (org, |org - pred|) as an exact-integer fp16 pair: EncCu.cpp:816,827 (u16 cast), :833 (absdiff),
 // :848-867 (clip to [0,1] after the 1/1023 scale == clip the integer to [0,1023]; the scale itself
@@ -2126,8 +2126,19 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   CONV_CASE2(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
+bool mlt_conv_has_centre_variant(int cin, int cout) { return cin == cout && (cin == 128 || cin == 256); }
+
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
   const bool dma = variant == MLT_CONV_DMA;
+  if (variant == MLT_CONV_CENTRE) {  // stride-1 layers of the small-CU models on 1x1 maps: centre tap only (TAPS = 1), 128 samples per tile
+    if (cin == 128 && cout == 128 && stride == 1)
+      return exact ? launch_conv_t<128, 128, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
+                   : launch_conv_t<128, 128, 1, 1, false, 64, 1, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st);
+    if (cin == 256 && cout == 256 && stride == 1)
+      return exact ? launch_conv_t<256, 256, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
+                   : launch_conv_t<256, 256, 1, 1, false, 64, 1, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st);
+    return hipErrorInvalidValue;
+  }
 #if CFG_LAT
   if (variant == MLT_CONV_LATENCY && !exact) {  // 32 couts x 128 pixels per 4-wave workgroup, weights packed for CBP = 4
     if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 64, 1, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);

@@ -205,7 +205,7 @@ static void pack_stem5(PackedConv &pc, const float *ws, const float *w1, const s
     }
 }
 
-bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::string &err) {
+bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m, std::string &err) {
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
   if (std::memcmp(h->magic, "MLTW", 4) != 0 || h->version != 1 || h->arch > 1) { err = "not an MLTW v1 blob"; return false; }
@@ -257,6 +257,18 @@ bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::stri
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, wname);
         const float *w = b.find(nm, (uint64_t)c * ci * 9, err);
         if (!w) return false;
+        // A 3x3 pad-1 stride-1 conv on a 1x1 map touches only its centre tap (the other eight multiply the zero padding),
+        // so for the stages that run on 1x1 maps at this CU size only that tap is packed and the kernel runs as a 1x1 conv:
+        // bit-identical result (the dropped products are exact zeros), 9x less weight traffic and MFMA work.
+        std::vector<float> centre;
+        const int hmap = (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1;  // output height of stage s
+        if (stride == 1 && !with_sc && hmap == 1 && mlt_conv_has_centre_variant(ci, c)) {
+          centre.resize((size_t)c * ci);
+          for (size_t k = 0; k < centre.size(); ++k) centre[k] = w[k * 9 + 4];
+          w = centre.data();
+          pc.taps = 1;
+          pc.gt = 1;
+        }
         std::vector<double> scale, scale_sc;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, bnname);
         fold_scale(b, nm, c, scale, pc.bias, err);

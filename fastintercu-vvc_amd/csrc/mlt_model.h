@@ -49,7 +49,7 @@ struct Model {
   bool on_device = false;
 };
 
-bool build_model(const void *blob, size_t bytes, bool exact, Model &m, std::string &err);
+bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m, std::string &err);  // size: CU size the model will serve
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
 
