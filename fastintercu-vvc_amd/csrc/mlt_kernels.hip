@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
   static_assert(TT % GT == 0, "tap grouping");
   static_assert(COUT % CT == 0, "cout tiling");
-  static_assert(!SC || (STRIDE == 2 && TAPS == 9), "shortcut rides on stride-2 3x3 convs");
+  static_assert(!SC || (STRIDE == 2 && (TAPS == 9 || TAPS == 1)), "shortcut rides on stride-2 convs (3x3, or its centre tap on a 1x1 input)");
   static_assert(RB >= 1 && RB <= 4, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2126,7 +2126,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   CONV_CASE2(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF)
 
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
-bool mlt_conv_has_centre_variant(int cin, int cout) { return cin == cout && (cin == 128 || cin == 256); }
+bool mlt_conv_has_centre_variant(int cin, int cout) { return (cin == cout && (cin == 128 || cin == 256)) || (cin == 128 && cout == 256); }
 
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
   const bool dma = variant == MLT_CONV_DMA;
@@ -2134,6 +2134,9 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
     if (cin == 128 && cout == 128 && stride == 1)
       return exact ? launch_conv_t<128, 128, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
                    : launch_conv_t<128, 128, 1, 1, false, 64, 1, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2)  // 1x1 input: centre tap + projection shortcut, both 1x1 on the same pixel
+      return exact ? launch_conv_t<128, 256, 2, 1, true, 32, 2, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 1, 2, 3, 1, false>(a, grid_x, extra_lds, st)
+                   : launch_conv_t<128, 256, 2, 1, true, 32, 1, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 1, 2, 5, 1, false>(a, grid_x, extra_lds, st);
     if (cin == 256 && cout == 256 && stride == 1)
       return exact ? launch_conv_t<256, 256, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
                    : launch_conv_t<256, 256, 1, 1, false, 64, 1, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st);

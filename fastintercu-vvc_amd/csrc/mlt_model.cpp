@@ -262,7 +262,9 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
         // bit-identical result (the dropped products are exact zeros), 9x less weight traffic and MFMA work.
         std::vector<float> centre;
         const int hmap = (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1;  // output height of stage s
-        if (stride == 1 && !with_sc && hmap == 1 && mlt_conv_has_centre_variant(ci, c)) {
+        const int hin = (size >> s) > 0 ? (size >> s) : 1;  // input height of stage s
+        // (the same holds for the stride-2 conv + shortcut of a stage whose INPUT is 1x1: every tap but the centre is padding)
+        if (((stride == 1 && !with_sc && hmap == 1) || (stride == 2 && with_sc && hin == 1)) && mlt_conv_has_centre_variant(ci, c)) {
           centre.resize((size_t)c * ci);
           for (size_t k = 0; k < centre.size(); ++k) centre[k] = w[k * 9 + 4];
           w = centre.data();
