@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""CPU baseline per SURVEY.md §8(d) -- TEST / MEASUREMENT INFRASTRUCTURE ONLY (same import rules as oracle.py).
+
+"The reference's CPU libtorch path" = the same graph on host cores (EncCu.cpp:894-909 with at::kCPU).  The reference
+modules cannot travel to the GPU box, so this times oracle/torch_port.py -- the restatement on PyTorch's CPU operators
+(oneDNN convolutions), i.e. the kernels LibTorch-CPU would dispatch -- the way §8(d) prescribes:
+  * batch 1 (the encoder's call pattern) and batch 64 in ONE process with torch.set_num_threads(physical cores),
+  * the batch-4096 workload sharded over P worker processes x T threads with P*T = physical cores (one process with
+    256 threads oversubscribes oneDNN's per-primitive parallelism: measured 3.6 CU/s in round 1), on a bounded sample,
+  * 3 warm-ups, median of >= 10 timed runs; cores, CPU model, P and T reported.
+Prints one JSON object (last line of stdout) when --json is given.  Never touches the GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cpu_info():
+    model, pairs = "unknown", set()
+    phys = core = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical = min(len(pairs), logical) if pairs else max(logical // 2, 1)
+    return model, physical, logical
+
+
+def _worker(rank, T, size, first, count, runs, warm, bar, blob):
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import mltcnn_pkg
+    from oracle.torch_port import TorchPort
+    pkg = mltcnn_pkg.load()
+    torch.set_num_threads(T)
+    port = TorchPort(blob)
+    org, pred = pkg.synth.make_patches_bulk(size, count, 0xC0FFEE, first=first)
+    poc, qp = pkg.synth.make_scalars(count, 0xC0FFEE, first=first)
+    for i in range(warm + runs):
+        bar.wait()
+        port.forward(org, pred, poc, qp, chunk=64)
+        bar.wait()
+
+
+def sharded(size, blob, P, T, per_proc, runs, warm):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    bar = ctx.Barrier(P + 1)
+    procs = [ctx.Process(target=_worker, args=(r, T, size, r * per_proc, per_proc, runs, warm, bar, blob)) for r in range(P)]
+    for p in procs:
+        p.start()
+    times = []
+    for i in range(warm + runs):
+        bar.wait(timeout=600)
+        t0 = time.perf_counter()
+        bar.wait(timeout=600)
+        if i >= warm:
+            times.append(time.perf_counter() - t0)
+    for p in procs:
+        p.join(timeout=60)
+    return times
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--threads", type=int, default=0, help="T: threads per worker process of the sharded run (default 8)")
+    ap.add_argument("--procs", type=int, default=0, help="P: worker processes (default physical cores / T)")
+    ap.add_argument("--per-proc", type=int, default=64, help="CUs each worker evaluates per run (sample = P * this)")
+    ap.add_argument("--runs", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args()
+    model, physical, logical = cpu_info()
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import mltcnn_pkg
+    from oracle.torch_port import TorchPort
+    pkg = mltcnn_pkg.load()
+    size = args.size
+    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 10)
+    rows = []
+    # ---- one process, threads = physical cores: batch 1 (encoder-realistic) and batch 64 ----
+    torch.set_num_threads(physical)
+    port = TorchPort(blob)
+    org, pred = pkg.synth.make_patches_bulk(size, 64, 0xC0FFEE)
+    poc, qp = pkg.synth.make_scalars(64, 0xC0FFEE)
+    for b in (1, 64):
+        ts = []
+        for i in range(args.warmup + args.runs):
+            t0 = time.perf_counter()
+            port.forward(org[:b], pred[:b], poc[:b], qp[:b], chunk=64)
+            if i >= args.warmup:
+                ts.append(time.perf_counter() - t0)
+        med = statistics.median(ts)
+        rows.append({"impl": "torch-CPU port (oracle/torch_port.py, oneDNN fp32)", "batch": b, "procs": 1, "threads": physical,
+                     "value": round(b / med, 2), "median_s": round(med, 5), "runs": args.runs, "warmup": args.warmup})
+    # ---- the batch workload sharded over P processes x T threads ----
+    T = args.threads or min(8, physical)
+    P = args.procs or max(physical // T, 1)
+    times = sharded(size, blob, P, T, args.per_proc, args.runs, args.warmup)
+    med = statistics.median(times)
+    n = P * args.per_proc
+    rows.append({"impl": "torch-CPU port (oracle/torch_port.py, oneDNN fp32)", "batch": f"{n} (sample of the 4096-CU batch, {args.per_proc} per process)",
+                 "procs": P, "threads": T, "value": round(n / med, 2), "median_s": round(med, 5), "runs": args.runs, "warmup": args.warmup})
+    best = max(rows, key=lambda r: r["value"])
+    out = {"value": best["value"], "unit": "CU-inferences/s", "cores": best["procs"] * best["threads"], "kind": "port",
+           "sample": f"{best['batch']} CUs per run, {best['procs']} processes x {best['threads']} threads, median of {args.runs} after {args.warmup} warm-ups",
+           "cpu_model": model, "physical_cores": physical, "logical_cpus": logical, "rows": rows}
+    if args.json:
+        print(json.dumps(out))
+    else:
+        print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
