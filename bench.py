@@ -148,6 +148,7 @@ def main():
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "devices": devs,
                 "weight_blob_bytes": len(blob), "weight_broadcast_ms": round(bcast_ms, 3)}
     m = pkg.MltCnn(device=dev_index, sizes=(size,), blobs={size: blob}, max_batch=B, flags=args.flags)
+    arith = m.arithmetic(size)  # fast or exact (load-time calibration), guards
 
     # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
     org, pred = pkg.synth.make_patches_bulk(size, B, 0xC0FFEE, first=rank * B)
@@ -329,7 +330,8 @@ def main():
                   "split_identical": bool(not (mism & decisive).any()),
                   "oracle": "oracle/mlt_oracle.c (fp32 restatement pinned to the reference fixtures)"}
 
-    exact = (size == 128 and args.flags & 1) or (size != 128 and not args.flags & 2)
+    exact = bool(arith["exact"])
+    arith = m.arithmetic(size)
     out = {
         "metric": f"CU-inferences/sec (batch {B}, {size}x{size})", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -338,7 +340,10 @@ def main():
         "config": {"workload": f"BASELINE configs[{1 if size == 128 else 2}]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
                    "batch_per_gpu": B, "cu_size": size, "weights": "synthetic seed 10 (no trained checkpoint is distributed)",
-                   "parallelism": f"shard{world}"},
+                   "parallelism": f"shard{world}",
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else "fast (single fp16 pass) + flat-content guard" + (" + decision guard" if arith["decision_guard"] else ""),
+                                  "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
+                                  "guard_reruns_total": arith["guard_reruns"]}},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,

@@ -19,8 +19,10 @@ ERR_NAMES = {1: "MLT_ERR_ARG", 2: "MLT_ERR_NO_DEVICE", 3: "MLT_ERR_WEIGHTS", 4: 
 SIZE_BITS = {128: 1, 64: 2, 32: 4, 16: 8}
 FLAG_EXACT_128 = 0x1   # 128x128 in exact (fp16 hi+lo, 3-pass) arithmetic instead of fast
 FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
-FLAG_DECISION_GUARD = 0x4  # host entry points re-evaluate near-tie CUs with the exact arithmetic
-EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "mlt_predict_batch",
+FLAG_DECISION_GUARD = 0x4  # CUs with a near-tie on the decision head are re-evaluated with the exact arithmetic
+FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (measurement only)
+FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
+EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
 
@@ -28,7 +30,12 @@ EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_predict", "ml
 class MltConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("weights_dir", C.c_char_p),
                 ("size_mask", C.c_uint32), ("head_index", C.c_int32 * 4), ("max_batch", C.c_int32),
-                ("flags", C.c_uint32), ("guard_margin", C.c_float)]
+                ("flags", C.c_uint32), ("guard_margin", C.c_float), ("tolerance", C.c_float), ("reserved", C.c_uint32)]
+
+
+class MltArithInfo(C.Structure):
+    _fields_ = [("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
+                ("flat_guard", C.c_int32), ("decision_guard", C.c_int32), ("guard_reruns", C.c_uint64)]
 
 
 class MltKernelTime(C.Structure):
@@ -66,6 +73,7 @@ def load_library():
     lib.mlt_abi_version.restype = i32
     lib.mlt_init.argtypes = [C.POINTER(MltConfig), C.POINTER(vp)]
     lib.mlt_load_weights.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.mlt_arithmetic.argtypes = [vp, i32, C.POINTER(MltArithInfo)]
     lib.mlt_predict.argtypes = [vp, vp, i32, vp, i32, i32, C.c_int32, C.c_int32, vp, vp]
     lib.mlt_predict_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mlt_predict_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -92,7 +100,8 @@ class MltCnn:
     """One context = one HIP device + one stream (one per encoder thread / EncCu instance)."""
 
     def __init__(self, device: int = 0, sizes=(128,), weights_dir: str | None = None, blobs: dict | None = None,
-                 head_index: dict | None = None, max_batch: int = 4096, flags: int = 0, guard_margin: float = 0.0):
+                 head_index: dict | None = None, max_batch: int = 4096, flags: int = 0, guard_margin: float = 0.0,
+                 tolerance: float = 0.0):
         self._lib = load_library()
         cfg = MltConfig()
         cfg.struct_size = C.sizeof(MltConfig)
@@ -104,6 +113,7 @@ class MltCnn:
         cfg.max_batch = max_batch
         cfg.flags = flags
         cfg.guard_margin = guard_margin
+        cfg.tolerance = tolerance
         self._h = C.c_void_p()
         rc = self._lib.mlt_init(C.byref(cfg), C.byref(self._h))
         if rc != MLT_OK:
@@ -130,6 +140,12 @@ class MltCnn:
     def load_weights(self, size: int, blob: bytes):
         buf = C.create_string_buffer(blob, len(blob))
         self._check(self._lib.mlt_load_weights(self._h, size, buf, len(blob)))
+
+    def arithmetic(self, size: int) -> dict:
+        """Arithmetic the size runs after loading (fast / exact), what the calibration measured, guard activity."""
+        info = MltArithInfo()
+        self._check(self._lib.mlt_arithmetic(self._h, size, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_}
 
     def num_logits(self, size: int) -> int:
         return self._lib.mlt_num_logits(size)

@@ -8,6 +8,7 @@
 // There is NO CPU fallback: without a usable HIP device mlt_init fails with MLT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,10 +38,24 @@ int size_index(int size) {
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct SizeState {
-  bool enabled = false, loaded = false, exact = false, guard = false;
+  bool enabled = false, loaded = false;
+  bool exact = false;          // arithmetic `model` runs (after calibration)
+  bool want_exact = false;     // configured arithmetic (flags)
+  bool flat_guard = false, margin_guard = false, calibrate = false;
+  bool calibrated = false;
+  float calib_rms = 0.f, calib_max = 0.f;
+  uint64_t reruns = 0;         // CUs re-evaluated by the guards
   int size = 0, head_index = 0;
   mlt::Model model;
-  mlt::Model model_exact;  // decision guard: exact-arithmetic copy used to re-evaluate near-tie CUs
+  mlt::Model model_exact;      // fast sizes: exact-arithmetic copy the guards re-evaluate flagged CUs with
+  bool guards() const { return !exact && (flat_guard || margin_guard) && model_exact.on_device; }
+};
+
+// device-side guard state of one in-flight batch (mlt_kernels.hip: flat_stat / guard_select kernels)
+struct GuardSlot {
+  int32_t *d_flat = nullptr, *d_idx = nullptr, *d_count = nullptr;
+  float *d_lg = nullptr;       // logits for the margin test when the caller wants none
+  int32_t *h_count = nullptr;  // pinned
 };
 
 // mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
@@ -65,6 +80,7 @@ struct Deferred {
   int n_launched[2] = {0, 0};               // CUs of the generation occupying each set (0: never launched)
   uint64_t gen_of_set[2] = {~0ull, ~0ull};
   hipEvent_t done[2] = {nullptr, nullptr};
+  bool guard_pending[2] = {false, false};   // set's batch ran with guards and its flagged CUs have not been re-evaluated yet
 };
 
 struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
@@ -92,6 +108,14 @@ struct mlt_ctx {
   // staging for the host-pointer entry points
   char *stage = nullptr;
   size_t stage_bytes = 0;
+  // parity guards: selection buffers for two in-flight batches, gather staging for the flagged CUs
+  float tolerance = 1e-3f;
+  char *guard_dev = nullptr;
+  size_t guard_slot_bytes = 0;
+  int guard_cap_n = 0, guard_cap_nl = 0;
+  int32_t *guard_host = nullptr;  // pinned: two counters
+  char *gstage = nullptr;
+  size_t gstage_bytes = 0;
   std::string err;
   bool profile = false;
   std::map<std::string, ProfAcc> prof;
@@ -474,21 +498,184 @@ int ensure_stage(mlt_ctx *ctx, size_t bytes) {
   return MLT_OK;
 }
 
-// Decision guard (MLT_FLAG_DECISION_GUARD): indices of the CUs whose decision-head top-2 margin is below the threshold.
-void guard_select(const SizeState &st, float margin, int n, const float *logits, std::vector<int> &idx) {
-  const mlt::Model &m = st.model;
-  int off = 0;
-  for (int h = 0; h < st.head_index; ++h) off += m.heads[h].classes;
-  const int k = m.heads[st.head_index].classes, nl = m.n_logits;
-  idx.clear();
-  for (int i = 0; i < n; ++i) {
-    const float *l = logits + (size_t)i * nl + off;
-    float a = -3.4e38f, b = -3.4e38f;
-    for (int c = 0; c < k; ++c) {
-      if (l[c] > a) { b = a; a = l[c]; } else if (l[c] > b) b = l[c];
-    }
-    if (!(a - b >= margin)) idx.push_back(i);  // also catches NaN
+// ---- parity guards (include/mltcnn.h: flat guard, decision guard) --------------------------------------------------
+// Per batch: [flat_stat_kernel] -> fast network -> guard_select_kernel (ascending list of flagged CUs + count) -> 4-byte
+// D2H of the count.  Once the host knows the count k it enqueues, for k > 0: gather of the flagged CUs' planes -> exact
+// network on k CUs -> scatter of their split modes / logits over the fast results.
+
+int guard_slot(mlt_ctx *ctx, int which, int n, int nl, GuardSlot *g) {
+  if (n > ctx->guard_cap_n || nl > ctx->guard_cap_nl || !ctx->guard_dev) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->guard_dev) (void)hipFree(ctx->guard_dev);
+    ctx->guard_dev = nullptr;
+    const int cn = n > ctx->guard_cap_n ? n : ctx->guard_cap_n, cl = nl > ctx->guard_cap_nl ? nl : ctx->guard_cap_nl;
+    const size_t ints = ((size_t)cn * 4 + 255) / 256 * 256;
+    ctx->guard_slot_bytes = 2 * ints + 256 + ((size_t)cn * cl * 4 + 255) / 256 * 256;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->guard_dev, 2 * ctx->guard_slot_bytes));
+    ctx->guard_cap_n = cn; ctx->guard_cap_nl = cl;
   }
+  if (!ctx->guard_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->guard_host, 64, hipHostMallocDefault));
+  const size_t ints = ((size_t)ctx->guard_cap_n * 4 + 255) / 256 * 256;
+  char *base = ctx->guard_dev + (size_t)which * ctx->guard_slot_bytes;
+  g->d_flat = (int32_t *)base; g->d_idx = (int32_t *)(base + ints); g->d_count = (int32_t *)(base + 2 * ints);
+  g->d_lg = (float *)(base + 2 * ints + 256);
+  g->h_count = ctx->guard_host + which;
+  return MLT_OK;
+}
+
+struct Planes {  // the two Pel planes of a batch in device memory (element strides)
+  const int16_t *org, *pred;
+  long org_rs, org_cs, pred_rs, pred_cs;
+  bool aligned8() const { return (((uintptr_t)org | (uintptr_t)pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0; }
+};
+
+// fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
+// (pinned) -- valid after the stream has been synchronised.  d_logits may be NULL.
+int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split,
+                      float *d_logits, const GuardSlot &g) {
+  const int S = st.size, nl = st.model.n_logits;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc;
+  if (st.flat_guard) {
+    FlatStatArgs fa{};
+    fa.org = pl.org; fa.pred = pl.pred; fa.org_row_stride = pl.org_rs; fa.org_cu_stride = pl.org_cs; fa.pred_row_stride = pl.pred_rs;
+    fa.pred_cu_stride = pl.pred_cs; fa.flat = g.d_flat; fa.n = n; fa.s_l = ilog2(S);
+    if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
+    HIP_TRY(ctx, mlt_launch_flat_stat(fa, pl.aligned8(), ctx->stream));
+    if ((rc = L.prof_end(e1))) return rc;
+  }
+  float *lg = d_logits ? d_logits : (st.margin_guard ? g.d_lg : nullptr);
+  if ((rc = run_network(ctx, st, st.model, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg))) return rc;
+  GuardSelectArgs sa{};
+  sa.flat = st.flat_guard ? g.d_flat : nullptr;
+  sa.logits = st.margin_guard ? lg : nullptr;
+  sa.idx = g.d_idx; sa.count = g.d_count; sa.n = n; sa.n_logits = nl;
+  int off = 0;
+  for (int h = 0; h < st.head_index; ++h) off += st.model.heads[h].classes;
+  sa.head_off = off; sa.head_classes = st.model.heads[st.head_index].classes;
+  sa.flat_thr = (S * S / 4) / 8;  // >= 1/8 of the quads
+  sa.margin = st.margin_guard ? ctx->guard_margin : 0.f;
+  if ((rc = L.prof_begin("guard_select", 0.0, 0.0, e0, e1))) return rc;
+  HIP_TRY(ctx, mlt_launch_guard_select(sa, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(g.h_count, g.d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  return MLT_OK;
+}
+
+// k > 0 flagged CUs (g.d_idx) of a batch whose fast results are in d_split / d_logits: exact re-evaluation, asynchronous.
+int guard_fixup_async(mlt_ctx *ctx, SizeState &st, int k, const Planes &pl, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split,
+                      float *d_logits, const GuardSlot &g) {
+  const int S = st.size, nl = st.model.n_logits;
+  const size_t cs = (size_t)S * S;
+  const size_t plane = (cs * 2 * k + 255) / 256 * 256, small = ((size_t)k * 4 + 255) / 256 * 256, lgb = ((size_t)k * nl * 4 + 255) / 256 * 256;
+  const size_t need = 2 * plane + 3 * small + lgb;
+  if (need > ctx->gstage_bytes) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->gstage) (void)hipFree(ctx->gstage);
+    ctx->gstage = nullptr; ctx->gstage_bytes = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->gstage, need));
+    ctx->gstage_bytes = need;
+  }
+  GuardGatherArgs ga{};
+  ga.org = pl.org; ga.pred = pl.pred; ga.org_row_stride = pl.org_rs; ga.org_cu_stride = pl.org_cs; ga.pred_row_stride = pl.pred_rs; ga.pred_cu_stride = pl.pred_cs;
+  ga.poc = d_poc; ga.qp = d_qp; ga.idx = g.d_idx; ga.k = k; ga.s_l = ilog2(S);
+  ga.g_org = (int16_t *)ctx->gstage; ga.g_pred = (int16_t *)(ctx->gstage + plane);
+  ga.g_poc = (int32_t *)(ctx->gstage + 2 * plane); ga.g_qp = (int32_t *)(ctx->gstage + 2 * plane + small);
+  int32_t *g_split = (int32_t *)(ctx->gstage + 2 * plane + 2 * small);
+  float *g_lg = (float *)(ctx->gstage + 2 * plane + 3 * small);
+  HIP_TRY(ctx, mlt_launch_guard_gather(ga, ctx->stream));
+  int rc = run_network(ctx, st, st.model_exact, k, ga.g_org, S, (long)cs, ga.g_pred, S, (long)cs, ga.g_poc, ga.g_qp, g_split, g_lg);
+  if (rc) return rc;
+  GuardScatterArgs sc{};
+  sc.idx = g.d_idx; sc.g_split = g_split; sc.g_logits = g_lg; sc.split = d_split; sc.logits = d_logits; sc.k = k; sc.n_logits = nl;
+  HIP_TRY(ctx, mlt_launch_guard_scatter(sc, ctx->stream));
+  st.reruns += (uint64_t)k;
+  return MLT_OK;
+}
+
+// network for n CUs with whatever guards the size has; synchronises once when guards are on (see mlt_predict_batch_device).
+int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
+  if (!st.guards())
+    return run_network(ctx, st, st.model, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, d_logits);
+  GuardSlot g;
+  int rc = guard_slot(ctx, 0, n, st.model.n_logits, &g);
+  if (rc) return rc;
+  if ((rc = run_guarded_async(ctx, st, n, pl, d_poc, d_qp, d_split, d_logits, g))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int k = *g.h_count;
+  if (k < 0 || k > n) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
+  return k ? guard_fixup_async(ctx, st, k, pl, d_poc, d_qp, d_split, d_logits, g) : MLT_OK;
+}
+
+// ---- load-time calibration of the fast arithmetic against the exact one (include/mltcnn.h: mlt_load_weights) ----
+int calibrate(mlt_ctx *ctx, SizeState &st) {
+  const int S = st.size, n = 48, nl = st.model.n_logits;
+  const size_t cs = (size_t)S * S;
+  std::vector<int16_t> org(cs * n), pred(cs * n);
+  std::vector<int32_t> poc(n), qp(n);
+  uint64_t z = 0x9E3779B97F4A7C15ull;  // splitmix64: blocky base + texture, pred = org + noise (the bench / fixture "texture" kind)
+  auto next = [&]() { z += 0x9E3779B97F4A7C15ull; uint64_t x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
+  const int nb = S / 16 > 0 ? S / 16 : 1, bs = S / nb;
+  for (int i = 0; i < n; ++i) {
+    std::vector<int> base((size_t)nb * nb);
+    for (int &b : base) b = 64 + (int)(next() % 896);
+    for (int y = 0; y < S; ++y)
+      for (int x = 0; x < S; ++x) {
+        int o = base[(size_t)(y / bs) * nb + x / bs] + (int)(next() % 97) - 48;
+        o = o < 0 ? 0 : o > 1023 ? 1023 : o;
+        int q = o + (int)(next() % 81) - 40;
+        q = q < 0 ? 0 : q > 1023 ? 1023 : q;
+        org[(size_t)i * cs + (size_t)y * S + x] = (int16_t)o;
+        pred[(size_t)i * cs + (size_t)y * S + x] = (int16_t)q;
+      }
+    poc[i] = (int32_t)(next() % 601);
+    qp[i] = 17 + (int32_t)(next() % 31);
+  }
+  const size_t plane = cs * 2 * n, lgb = (size_t)n * nl * 4;
+  char *d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d, 2 * plane + 3 * (size_t)n * 4 + 2 * lgb));
+  int16_t *d_org = (int16_t *)d, *d_pred = (int16_t *)(d + plane);
+  int32_t *d_poc = (int32_t *)(d + 2 * plane), *d_qp = d_poc + n, *d_split = d_qp + n;
+  float *d_lf = (float *)(d_split + n), *d_le = d_lf + (size_t)n * nl;
+  std::vector<float> lf((size_t)n * nl), le((size_t)n * nl);
+  int rc = MLT_OK;
+  auto run = [&]() -> int {
+    HIP_TRY(ctx, hipMemcpy(d_org, org.data(), plane, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_pred, pred.data(), plane, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_poc, poc.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_qp, qp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    int r = run_network(ctx, st, st.model, n, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf);
+    if (r) return r;
+    if ((r = run_network(ctx, st, st.model_exact, n, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_le))) return r;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(lf.data(), d_lf, lgb, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(le.data(), d_le, lgb, hipMemcpyDeviceToHost));
+    return MLT_OK;
+  };
+  const bool prof = ctx->profile;
+  ctx->profile = false;
+  rc = run();
+  ctx->profile = prof;
+  (void)hipFree(d);
+  if (rc) return rc;
+  double s2 = 0.0, mx = 0.0;
+  for (size_t i = 0; i < lf.size(); ++i) {
+    const double e = std::fabs((double)lf[i] - (double)le[i]);
+    s2 += e * e;
+    if (!(e <= mx)) mx = e;  // NaN -> mx = NaN -> fails the test below
+  }
+  st.calibrated = true;
+  st.calib_rms = (float)std::sqrt(s2 / (double)lf.size());
+  st.calib_max = (float)mx;
+  return MLT_OK;
+}
+
+void drop_graphs(mlt_ctx *ctx, int si) {  // a captured kernel chain bakes in weight / workspace pointers
+  SingleCu &sg = ctx->single[si];
+  if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+  if (sg.graph) (void)hipGraphDestroy(sg.graph);
+  sg.exec = nullptr; sg.graph = nullptr;
 }
 
 }  // namespace
@@ -509,23 +696,51 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   SizeState &st = ctx->sz[si];
   if (!st.enabled) { ctx->err = "CU size not enabled in size_mask"; return MLT_ERR_SIZE_DISABLED; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
-  mlt::Model m;
   std::string err;
-  if (!mlt::build_model(blob, bytes, st.exact, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  mlt::Model m;
+  if (!mlt::build_model(blob, bytes, st.want_exact, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
-  if (st.loaded) { (void)hipStreamSynchronize(ctx->stream); free_model(st.model); free_model(st.model_exact); st.loaded = false; }
+  if (st.head_index < 0 || st.head_index >= m.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
+  // a reload replaces device buffers that captured graphs and in-flight work point to
+  (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx, si);
+  if (st.loaded) { free_model(st.model); free_model(st.model_exact); st.loaded = false; }
+  st.exact = st.want_exact;
+  st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   int rc = upload_model(ctx, st.model);
   if (rc) return rc;
-  if (st.guard && !st.exact) {
+  if (!st.exact && (st.flat_guard || st.margin_guard || st.calibrate)) {
     mlt::Model me;
     if (!mlt::build_model(blob, bytes, true, size, me, err)) { ctx->err = "weights (exact copy): " + err; return MLT_ERR_WEIGHTS; }
-    if (st.model_exact.on_device) free_model(st.model_exact);
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return rc;
+    if (st.calibrate) {
+      if ((rc = calibrate(ctx, st))) return rc;
+      const bool ok = 5.5f * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance;
+      if (!ok) {  // this weight set does not meet the contract with single-pass fp16: run it exact
+        free_model(st.model);
+        st.model = std::move(st.model_exact);
+        st.model_exact = mlt::Model();
+        st.exact = true;
+      }
+    }
   }
-  if (st.head_index < 0 || st.head_index >= st.model.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
   st.loaded = true;
+  return MLT_OK;
+}
+
+int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
+  if (!ctx || !out) return MLT_ERR_ARG;
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  out->exact = st->exact ? 1 : 0;
+  out->calibrated = st->calibrated ? 1 : 0;
+  out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;
+  out->flat_guard = (!st->exact && st->flat_guard) ? 1 : 0;
+  out->decision_guard = (!st->exact && st->margin_guard) ? 1 : 0;
+  out->guard_reruns = st->reruns;
   return MLT_OK;
 }
 
@@ -544,6 +759,7 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   ctx->device = cfg->device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
   if (cfg->guard_margin > 0.f) ctx->guard_margin = cfg->guard_margin;
+  if (cfg->tolerance > 0.f) ctx->tolerance = cfg->tolerance;
   if (const char *e = std::getenv("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
   if (const char *e = std::getenv("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
   if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
@@ -563,8 +779,11 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     st.enabled = (mask >> i) & 1u;
     // precision: 128 -> fast (single fp16 pass) unless MLT_FLAG_EXACT_128; 64/32/16 -> exact (fp16 hi+lo pairs, 3 passes)
     // unless MLT_FLAG_FAST_SMALL.  See DESIGN.md "Numerics".
-    st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
-    st.guard = (cfg->flags & MLT_FLAG_DECISION_GUARD) != 0;
+    st.want_exact = st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
+    st.margin_guard = (cfg->flags & MLT_FLAG_DECISION_GUARD) != 0;
+    st.flat_guard = (cfg->flags & MLT_FLAG_NO_FLAT_GUARD) == 0;
+    // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
+    st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];
@@ -611,6 +830,9 @@ void mlt_shutdown(mlt_ctx *ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (int b = 0; b < 2; ++b) { if (ctx->ev_h2d[b]) (void)hipEventDestroy(ctx->ev_h2d[b]); if (ctx->ev_done[b]) (void)hipEventDestroy(ctx->ev_done[b]); }
   if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->guard_dev) (void)hipFree(ctx->guard_dev);
+  if (ctx->gstage) (void)hipFree(ctx->gstage);
+  if (ctx->guard_host) (void)hipHostFree(ctx->guard_host);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -649,8 +871,8 @@ int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, c
   const long cs = (long)size * size;
   for (int i0 = 0; i0 < n; i0 += ctx->chunk) {
     const int c = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-    rc = run_network(ctx, *st, st->model, c, (const int16_t *)d_org + (size_t)i0 * cs, size, cs, (const int16_t *)d_pred + (size_t)i0 * cs, size, cs,
-                     (const int32_t *)d_poc + i0, (const int32_t *)d_qp + i0, (int32_t *)d_split_mode + i0,
+    const Planes pl{(const int16_t *)d_org + (size_t)i0 * cs, (const int16_t *)d_pred + (size_t)i0 * cs, size, cs, size, cs};
+    rc = run_checked(ctx, *st, c, pl, (const int32_t *)d_poc + i0, (const int32_t *)d_qp + i0, (int32_t *)d_split_mode + i0,
                      d_logits ? (float *)d_logits + (size_t)i0 * nl : nullptr);
     if (rc) return rc;
   }
@@ -682,107 +904,87 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
       HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[b], hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming));
+      if (!ctx->ev_done[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming));
     }
   }
-  int16_t *d_org, *d_pred;
-  int32_t *d_poc, *d_qp, *d_split;
-  float *d_lg;
-  auto use_set = [&](int b) {
+  struct Set { int16_t *d_org, *d_pred; int32_t *d_poc, *d_qp, *d_split; float *d_lg; };
+  auto set_of = [&](int b) {
     char *base = ctx->stage + (size_t)b * setbytes;
-    d_org = (int16_t *)base; d_pred = (int16_t *)(base + plane);
-    d_poc = (int32_t *)(base + 2 * plane); d_qp = (int32_t *)(base + 2 * plane + small);
-    d_split = (int32_t *)(base + 2 * plane + 2 * small);
-    d_lg = (float *)(base + 2 * plane + 3 * small);
+    return Set{(int16_t *)base, (int16_t *)(base + plane), (int32_t *)(base + 2 * plane), (int32_t *)(base + 2 * plane + small),
+               (int32_t *)(base + 2 * plane + 2 * small), (float *)(base + 2 * plane + 3 * small)};
   };
-  const bool guard = st->guard && !st->exact;
-  std::vector<float> own_lg;  // the guard selects on host logits; keep a private copy if the caller wants none
-  float *const user_logits = logits;
-  if (guard && !logits) { own_lg.resize((size_t)n * nl); logits = own_lg.data(); }
+  const bool guards = st->guards();
+  GuardSlot gs[2];
+  if (guards)
+    for (int b = 0; b < nset; ++b)
+      if ((rc = guard_slot(ctx, b, cap, nl, &gs[b]))) return rc;
   // Results come back through pinned buffers owned by the context: a D2H into the caller's (usually pageable) arrays
   // would block the host until the kernels are done and serialise the next sub-chunk's H2D behind them.
   const size_t hres_set = (size_t)cap * 4 + (size_t)cap * nl * 4;
-  if (nset == 2 && ctx->h_res_bytes < 2 * hres_set) {
+  if (ctx->h_res_bytes < 2 * hres_set) {
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     ctx->h_res = nullptr; ctx->h_res_bytes = 0;
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_res, 2 * hres_set, hipHostMallocDefault));
     ctx->h_res_bytes = 2 * hres_set;
   }
   int pend_i0[2] = {-1, -1}, pend_c[2] = {0, 0};
-  auto flush = [&](int b) -> int {  // sub-chunk in set b has completed: hand its results to the caller
+  auto fetch = [&](int b, int c) -> int {  // results of set b -> pinned (asynchronous)
+    const Set S = set_of(b);
+    char *hb = ctx->h_res + (size_t)b * hres_set;
+    HIP_TRY(ctx, hipMemcpyAsync(hb, S.d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits) HIP_TRY(ctx, hipMemcpyAsync(hb + (size_t)cap * 4, S.d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return MLT_OK;
+  };
+  auto flush = [&](int b) -> int {  // sub-chunk in set b has completed: guard fix-up if needed, then hand its results to the caller
     if (pend_i0[b] < 0) return MLT_OK;
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done[b]));
+    if (guards) {
+      const int k = *gs[b].h_count;
+      if (k < 0 || k > pend_c[b]) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
+      if (k > 0) {  // the set's inputs are still in place (the next H2D into it is issued after this flush)
+        const Set S = set_of(b);
+        const Planes pl{S.d_org, S.d_pred, size, (long)cs, size, (long)cs};
+        int r = guard_fixup_async(ctx, *st, k, pl, S.d_poc, S.d_qp, S.d_split, logits ? S.d_lg : nullptr, gs[b]);
+        if (r) return r;
+        if ((r = fetch(b, pend_c[b]))) return r;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      }
+    }
     const char *hb = ctx->h_res + (size_t)b * hres_set;
     std::memcpy(split_mode + pend_i0[b], hb, (size_t)pend_c[b] * 4);
     if (logits) std::memcpy(logits + (size_t)pend_i0[b] * nl, hb + (size_t)cap * 4, (size_t)pend_c[b] * nl * 4);
     pend_i0[b] = -1;
     return MLT_OK;
   };
+  if (!ctx->ev_done[0])
+    for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[b], hipEventDisableTiming));
   int k = 0;
   for (int i0 = 0; i0 < n; i0 += cap, ++k) {
     const int c = n - i0 < cap ? n - i0 : cap;
     const int b = nset == 2 ? (k & 1) : 0;
-    use_set(b);
+    const Set S = set_of(b);
     hipStream_t cps = nset == 2 ? ctx->copy_stream : ctx->stream;
-    if (nset == 2 && (rc = flush(b))) return rc;  // set b: sub-chunk k-2 fully drained (host-side wait)
-    HIP_TRY(ctx, hipMemcpyAsync(d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
-    HIP_TRY(ctx, hipMemcpyAsync(d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
-    HIP_TRY(ctx, hipMemcpyAsync(d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
-    HIP_TRY(ctx, hipMemcpyAsync(d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
+    if ((rc = flush(b))) return rc;  // set b: sub-chunk k-2 fully drained (host-side wait)
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_org, org + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_pred, pred + (size_t)i0 * cs, cs * 2 * c, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_poc, poc + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_qp, qp + i0, (size_t)c * 4, hipMemcpyHostToDevice, cps));
     if (nset == 2) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[b], cps));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[b], 0));
     }
-    if ((rc = run_network(ctx, *st, st->model, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
-    if (nset == 2) {
-      char *hb = ctx->h_res + (size_t)b * hres_set;
-      HIP_TRY(ctx, hipMemcpyAsync(hb, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (logits) HIP_TRY(ctx, hipMemcpyAsync(hb + (size_t)cap * 4, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_done[b], ctx->stream));
-      pend_i0[b] = i0; pend_c[b] = c;
-    } else {
-      HIP_TRY(ctx, hipMemcpyAsync(split_mode + i0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (logits) HIP_TRY(ctx, hipMemcpyAsync(logits + (size_t)i0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    const Planes pl{S.d_org, S.d_pred, size, (long)cs, size, (long)cs};
+    if (guards) rc = run_guarded_async(ctx, *st, c, pl, S.d_poc, S.d_qp, S.d_split, logits ? S.d_lg : nullptr, gs[b]);
+    else rc = run_network(ctx, *st, st->model, c, S.d_org, size, (long)cs, S.d_pred, size, (long)cs, S.d_poc, S.d_qp, S.d_split, logits ? S.d_lg : nullptr);
+    if (rc) return rc;
+    if ((rc = fetch(b, c))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_done[b], ctx->stream));
+    pend_i0[b] = i0; pend_c[b] = c;
   }
-  if (nset == 2) {
-    if ((rc = flush(k & 1))) return rc;        // older of the two pending sub-chunks first
-    if ((rc = flush((k & 1) ^ 1))) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
-  }
+  if ((rc = flush(k & 1))) return rc;        // older of the two pending sub-chunks first
+  if ((rc = flush((k & 1) ^ 1))) return rc;
+  if (nset == 2) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  use_set(0);
-  if (guard) {  // re-evaluate near-tie CUs with the exact arithmetic
-    const float *lg = logits;
-    std::vector<int> idx;
-    guard_select(*st, ctx->guard_margin, n, lg, idx);
-    if (!idx.empty()) {
-      const int k = (int)idx.size();
-      std::vector<int16_t> go((size_t)k * cs), gp((size_t)k * cs);
-      std::vector<int32_t> gpoc(k), gqp(k), gs(k);
-      std::vector<float> gl((size_t)k * nl);
-      for (int j = 0; j < k; ++j) {
-        std::memcpy(go.data() + (size_t)j * cs, org + (size_t)idx[j] * cs, cs * 2);
-        std::memcpy(gp.data() + (size_t)j * cs, pred + (size_t)idx[j] * cs, cs * 2);
-        gpoc[j] = poc[idx[j]]; gqp[j] = qp[idx[j]];
-      }
-      for (int j0 = 0; j0 < k; j0 += cap) {
-        const int c = k - j0 < cap ? k - j0 : cap;
-        HIP_TRY(ctx, hipMemcpyAsync(d_org, go.data() + (size_t)j0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_pred, gp.data() + (size_t)j0 * cs, cs * 2 * c, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_poc, gpoc.data() + j0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_qp, gqp.data() + j0, (size_t)c * 4, hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = run_network(ctx, *st, st->model_exact, c, d_org, size, (long)cs, d_pred, size, (long)cs, d_poc, d_qp, d_split, d_lg))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(gs.data() + j0, d_split, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(gl.data() + (size_t)j0 * nl, d_lg, (size_t)c * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      }
-      for (int j = 0; j < k; ++j) {
-        split_mode[idx[j]] = gs[j];
-        if (user_logits) std::memcpy(user_logits + (size_t)idx[j] * nl, gl.data() + (size_t)j * nl, (size_t)nl * 4);
-      }
-    }
-  }
   return MLT_OK;
 }
 
@@ -811,7 +1013,16 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
   h_sc[0] = poc; h_sc[1] = qp;
   HIP_TRY(ctx, hipMemcpyAsync(sg.d_stage, sg.h_stage, 2 * sg.plane + 8, hipMemcpyHostToDevice, ctx->stream));
   int16_t *d_org = (int16_t *)sg.d_stage, *d_pred = (int16_t *)(sg.d_stage + sg.plane);
-  int32_t *d_sc = (int32_t *)(sg.d_stage + 2 * sg.plane);
+  int32_t *d_sc = (int32_t *)(sg.d_stage + 2 * sg.plane);  // [poc, qp, split, flagged count, logits (<= 16) ..., flat, idx]
+  const Planes pl{d_org, d_pred, size, (long)cs, size, (long)cs};
+  const bool guards = st->guards();
+  GuardSlot g;
+  g.d_count = d_sc + 3; g.d_flat = d_sc + 20; g.d_idx = d_sc + 21; g.d_lg = (float *)(d_sc + 4); g.h_count = h_sc + 3;
+  auto chain = [&]() -> int {  // the kernel chain of one CU (captured into a hipGraph below)
+    if (!guards) return run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
+    int r = run_guarded_async(ctx, *st, 1, pl, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4), g);  // its 4-byte count D2H lands in h_sc[3]
+    return r;
+  };
   static const bool no_graph = std::getenv("MLT_NO_GRAPH") != nullptr || std::getenv("MLT_DEBUG_DUMP_DIR") != nullptr;
   bool replayed = false;
   if (!no_graph && !ctx->profile && ctx->own_stream) {
@@ -821,16 +1032,16 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
     }
     if (!sg.exec) {
       // first call: run eagerly once (allocates the workspace, configures every kernel), then capture the same chain
-      if ((rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+      if ((rc = chain())) return rc;
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
-        hipGraph_t g = nullptr;
-        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
-        if (rc == MLT_OK && ce == hipSuccess && g && hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
-          sg.graph = g; sg.ws_at_capture = ctx->ws; sg.stream_at_capture = ctx->stream;
+        rc = chain();
+        hipGraph_t gr = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &gr);
+        if (rc == MLT_OK && ce == hipSuccess && gr && hipGraphInstantiate(&sg.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+          sg.graph = gr; sg.ws_at_capture = ctx->ws; sg.stream_at_capture = ctx->stream;
         } else {
-          if (g) (void)hipGraphDestroy(g);
+          if (gr) (void)hipGraphDestroy(gr);
           sg.exec = nullptr;
           (void)hipGetLastError();
         }
@@ -841,17 +1052,13 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
       replayed = true;
     }
   }
-  if (!replayed && (rc = run_network(ctx, *st, st->model, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
+  if (!replayed && (rc = chain())) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (st->guard && !st->exact) {  // near-tie on the decision head: re-evaluate this CU with the exact arithmetic
-    std::vector<int> idx;
-    guard_select(*st, ctx->guard_margin, 1, (const float *)(h_sc + 4), idx);
-    if (!idx.empty()) {
-      if ((rc = run_network(ctx, *st, st->model_exact, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4)))) return rc;
-      HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
+  if (guards && h_sc[3] != 0) {  // flagged (flat content / near-tie on the decision head): re-evaluate with the exact arithmetic
+    if ((rc = guard_fixup_async(ctx, *st, 1, pl, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4), g))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h_sc + 2, d_sc + 2, (size_t)(2 + nl) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   *split_mode = h_sc[2];
   if (logits_opt) std::memcpy(logits_opt, h_sc + 4, (size_t)nl * 4);
@@ -860,10 +1067,20 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
 
 // ---- deferred single-CU prediction ----
 namespace {
+// device / pinned layout of one output set: split[CAP] | logits[CAP * nl] | flagged count (16 ints) | flat[CAP] | idx[CAP]
+struct DeferredOut { int32_t *split; float *lg; int32_t *count, *flat, *idx; };
+DeferredOut deferred_out(char *base, int nl) {
+  DeferredOut o;
+  o.split = (int32_t *)base; o.lg = (float *)(base + (size_t)MLT_DEFER_CAP * 4);
+  o.count = (int32_t *)(base + (size_t)MLT_DEFER_CAP * 4 * (1 + nl));
+  o.flat = o.count + 16; o.idx = o.flat + MLT_DEFER_CAP;
+  return o;
+}
+size_t deferred_fetch_bytes(int nl) { return (size_t)MLT_DEFER_CAP * 4 * (1 + nl) + 64; }
+
 int deferred_launch(mlt_ctx *ctx, SizeState *st, Deferred &df) {  // launch the accumulating generation as one batch
   if (df.n == 0) return MLT_OK;
   const int size = st->size, nl = st->model.n_logits, b = (int)(df.gen & 1), n = df.n;
-  const size_t cs = (size_t)size * size;
   char *hi = df.h_in + (size_t)b * df.in_set, *di = df.d_in + (size_t)b * df.in_set;
   char *ho = df.h_out + (size_t)b * df.out_set, *dout = df.d_out + (size_t)b * df.out_set;
   const size_t planes = (size_t)MLT_DEFER_CAP * df.plane;
@@ -872,18 +1089,48 @@ int deferred_launch(mlt_ctx *ctx, SizeState *st, Deferred &df) {  // launch the 
   HIP_TRY(ctx, hipMemcpyAsync(di + planes, hi + planes, (size_t)n * df.plane, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(di + 2 * planes, hi + 2 * planes, (size_t)MLT_DEFER_CAP * 8, hipMemcpyHostToDevice, ctx->stream));
   int32_t *d_poc = (int32_t *)(di + 2 * planes), *d_qp = d_poc + MLT_DEFER_CAP;
-  int32_t *d_split = (int32_t *)dout;
-  float *d_lg = (float *)(dout + (size_t)MLT_DEFER_CAP * 4);
-  const int rc = run_network(ctx, *st, st->model, n, (const int16_t *)di, size, (long)(df.plane / 2), (const int16_t *)(di + planes), size,
-                             (long)(df.plane / 2), d_poc, d_qp, d_split, d_lg);
+  const DeferredOut od = deferred_out(dout, nl), oh = deferred_out(ho, nl);
+  const Planes pl{(const int16_t *)di, (const int16_t *)(di + planes), size, (long)(df.plane / 2), size, (long)(df.plane / 2)};
+  int rc;
+  if (st->guards()) {
+    GuardSlot g;
+    g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.h_count = oh.count;
+    rc = run_guarded_async(ctx, *st, n, pl, d_poc, d_qp, od.split, od.lg, g);
+    df.guard_pending[b] = true;
+  } else {
+    rc = run_network(ctx, *st, st->model, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, od.split, od.lg);
+    df.guard_pending[b] = false;
+  }
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ho, dout, (size_t)MLT_DEFER_CAP * 4 + (size_t)n * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ho, dout, deferred_fetch_bytes(nl), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(df.done[b], ctx->stream));
   df.n_launched[b] = n;
   df.gen_of_set[b] = df.gen;
   ++df.gen;
   df.n = 0;
-  (void)cs;
+  return MLT_OK;
+}
+
+// first mlt_wait on a finished batch: re-evaluate its flagged CUs with the exact arithmetic (the set's inputs stay in place
+// until the set is reused two batches later)
+int deferred_guard_fixup(mlt_ctx *ctx, SizeState *st, Deferred &df, int b) {
+  if (!df.guard_pending[b]) return MLT_OK;
+  df.guard_pending[b] = false;
+  const int size = st->size, nl = st->model.n_logits;
+  char *di = df.d_in + (size_t)b * df.in_set, *ho = df.h_out + (size_t)b * df.out_set, *dout = df.d_out + (size_t)b * df.out_set;
+  const size_t planes = (size_t)MLT_DEFER_CAP * df.plane;
+  const DeferredOut od = deferred_out(dout, nl), oh = deferred_out(ho, nl);
+  const int k = *oh.count;
+  if (k == 0) return MLT_OK;
+  if (k < 0 || k > df.n_launched[b] || !st->guards()) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
+  int32_t *d_poc = (int32_t *)(di + 2 * planes), *d_qp = d_poc + MLT_DEFER_CAP;
+  const Planes pl{(const int16_t *)di, (const int16_t *)(di + planes), size, (long)(df.plane / 2), size, (long)(df.plane / 2)};
+  GuardSlot g;
+  g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.h_count = oh.count;
+  int rc = guard_fixup_async(ctx, *st, k, pl, d_poc, d_qp, od.split, od.lg, g);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ho, dout, deferred_fetch_bytes(nl), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MLT_OK;
 }
 }  // namespace
@@ -901,7 +1148,7 @@ int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *
   if (!df.h_in) {
     df.plane = ((size_t)size * size * 2 + 255) / 256 * 256;
     df.in_set = 2 * (size_t)MLT_DEFER_CAP * df.plane + (size_t)MLT_DEFER_CAP * 8;
-    df.out_set = ((size_t)MLT_DEFER_CAP * 4 * (1 + nl) + 255) / 256 * 256;
+    df.out_set = (deferred_fetch_bytes(nl) + (size_t)MLT_DEFER_CAP * 8 + 255) / 256 * 256;
     HIP_TRY(ctx, hipHostMalloc((void **)&df.h_in, 2 * df.in_set, hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc((void **)&df.h_out, 2 * df.out_set, hipHostMallocDefault));
     HIP_TRY(ctx, hipMalloc((void **)&df.d_in, 2 * df.in_set));
@@ -950,6 +1197,7 @@ int mlt_wait(mlt_ctx *ctx, int size, mlt_ticket ticket, int32_t *split_mode, flo
   if (gen == df.gen && (rc = deferred_launch(ctx, st, df))) return rc;  // still accumulating: launch it now
   if (df.gen_of_set[b] != gen || slot >= df.n_launched[b]) { ctx->err = "ticket expired (two newer batches were started)"; return MLT_ERR_ARG; }
   HIP_TRY(ctx, hipEventSynchronize(df.done[b]));
+  if ((rc = deferred_guard_fixup(ctx, st, df, b))) return rc;
   const char *ho = df.h_out + (size_t)b * df.out_set;
   *split_mode = ((const int32_t *)ho)[slot];
   if (logits_opt) std::memcpy(logits_opt, ho + (size_t)MLT_DEFER_CAP * 4 + (size_t)slot * nl * 4, (size_t)nl * 4);

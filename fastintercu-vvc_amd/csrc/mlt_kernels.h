@@ -78,6 +78,42 @@ struct HeadArgs {
   int32_t *split;  // [n]
 };
 
+// ---- parity guard (fast arithmetic): device-side selection of the CUs that are re-evaluated with the exact arithmetic ----
+struct FlatStatArgs {
+  const int16_t *org, *pred;   // Pel planes
+  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
+  int32_t *flat;               // [n] number of 4-pixel quads whose (org, |org-pred|) pairs are all identical
+  int n, s_l;                  // CU size S = 1 << s_l
+};
+struct GuardSelectArgs {
+  const int32_t *flat;         // [n] (FlatStatArgs.flat) or NULL
+  const float *logits;         // [n][n_logits] or NULL (margin test off)
+  int32_t *idx;                // [n] out: indices of the selected CUs, ascending
+  int32_t *count;              // [1] out
+  int n, n_logits, head_off, head_classes;
+  int flat_thr;                // select when flat >= flat_thr (flat != NULL)
+  float margin;                // select when top1 - top2 of the decision head < margin (logits != NULL, margin > 0)
+};
+struct GuardGatherArgs {
+  const int16_t *org, *pred;
+  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;
+  const int32_t *poc, *qp, *idx;
+  int16_t *g_org, *g_pred;     // dense [k][S][S]
+  int32_t *g_poc, *g_qp;       // [k]
+  int k, s_l;
+};
+struct GuardScatterArgs {
+  const int32_t *idx, *g_split;
+  const float *g_logits;
+  int32_t *split;              // [n]
+  float *logits;               // [n][n_logits] or NULL
+  int k, n_logits;
+};
+hipError_t mlt_launch_flat_stat(const FlatStatArgs &a, bool aligned8, hipStream_t st);
+hipError_t mlt_launch_guard_select(const GuardSelectArgs &a, hipStream_t st);
+hipError_t mlt_launch_guard_gather(const GuardGatherArgs &a, hipStream_t st);
+hipError_t mlt_launch_guard_scatter(const GuardScatterArgs &a, hipStream_t st);
+
 enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2, MLT_CONV_CENTRE = 3 };  // kernel variant of a layer shape
 bool mlt_conv_has_centre_variant(int cin, int cout);  // 1x1 (centre-tap) instantiation for stride-1 layers on 1x1 maps
 hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <utility>
 
 #include "mlt_kernels.h"
@@ -1889,9 +1890,116 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Parity guard of the fast arithmetic.  fp16 rounding noise is averaged away by the global pooling only where
+// neighbouring pixels DIFFER: on exactly-constant areas every pixel carries the same rounding error (measured: a constant
+// 128x128 CU reaches |dlogit| 1.3e-3, ordinary content 2-7e-4).  flat_stat_kernel counts, per CU, the aligned 4-pixel
+// quads whose (org, |org - pred|) pairs are all identical; guard_select_kernel lists the CUs whose count reaches the
+// threshold (and, optionally, those whose decision-head margin is small); the host runtime re-evaluates exactly those
+// CUs with the exact (hi, lo) arithmetic (gather -> exact network -> scatter).  Integer statistics: deterministic.
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void flat_stat_kernel(const FlatStatArgs a) {
+  __shared__ int wsum[4];
+  const int n = blockIdx.x, tid = threadIdx.x, S = 1 << a.s_l, qrow_l = a.s_l - 2;  // quads per row = S / 4
+  const int nquads = S << qrow_l;
+  const int16_t *o = a.org + (size_t)n * a.org_cu_stride, *p = a.pred + (size_t)n * a.pred_cu_stride;
+  int cnt = 0;
+  for (int q = tid; q < nquads; q += 256) {
+    const int y = q >> qrow_l, x = (q & ((1 << qrow_l) - 1)) * 4;
+    int16_t vo[4], vp[4];
+    if constexpr (ALIGNED) {
+      typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+      const uint2v wo = *(const uint2v *)(o + (size_t)y * a.org_row_stride + x), wp = *(const uint2v *)(p + (size_t)y * a.pred_row_stride + x);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { vo[j] = (int16_t)(wo[j >> 1] >> (16 * (j & 1))); vp[j] = (int16_t)(wp[j >> 1] >> (16 * (j & 1))); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { vo[j] = o[(size_t)y * a.org_row_stride + x + j]; vp[j] = p[(size_t)y * a.pred_row_stride + x + j]; }
+    }
+    const uint32_t w0 = prep_pair(vo[0], vp[0]);  // what the network sees (uint16 cast, absdiff, clip)
+    const bool flat = prep_pair(vo[1], vp[1]) == w0 && prep_pair(vo[2], vp[2]) == w0 && prep_pair(vo[3], vp[3]) == w0;
+    cnt += flat ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) a.flat[n] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one workgroup; ascending index list by a block-wide prefix scan (deterministic order)
+__global__ __launch_bounds__(1024) void guard_select_kernel(const GuardSelectArgs a) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, per = (a.n + 1023) / 1024, lo = tid * per, hi = lo + per < a.n ? lo + per : a.n;
+  auto selected = [&](int i) -> bool {
+    bool s = a.flat && a.flat[i] >= a.flat_thr;
+    if (a.logits && a.margin > 0.f) {
+      const float *l = a.logits + (size_t)i * a.n_logits + a.head_off;
+      float t1 = -3.4e38f, t2 = -3.4e38f;
+      for (int c = 0; c < a.head_classes; ++c) {
+        if (l[c] > t1) { t2 = t1; t1 = l[c]; } else if (l[c] > t2) t2 = l[c];
+      }
+      s = s || !(t1 - t2 >= a.margin);  // also catches NaN
+    }
+    return s;
+  };
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += selected(i) ? 1 : 0;
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - c;
+  for (int i = lo; i < hi; ++i)
+    if (selected(i)) a.idx[pos++] = i;
+  if (tid == 1023) *a.count = part[1023];
+}
+
+// grid (k, 2): plane blockIdx.y of the blockIdx.x-th selected CU -> dense staging
+__global__ __launch_bounds__(256) void guard_gather_kernel(const GuardGatherArgs a) {
+  const int j = blockIdx.x, src = a.idx[j], S = 1 << a.s_l, tid = threadIdx.x;
+  const bool is_pred = blockIdx.y == 1;
+  const int16_t *s = is_pred ? a.pred + (size_t)src * a.pred_cu_stride : a.org + (size_t)src * a.org_cu_stride;
+  const long rs = is_pred ? a.pred_row_stride : a.org_row_stride;
+  int16_t *d = (is_pred ? a.g_pred : a.g_org) + ((size_t)j << (2 * a.s_l));
+  for (int i = tid; i < S * S; i += 256) d[i] = s[(size_t)(i >> a.s_l) * rs + (i & (S - 1))];
+  if (tid == 0 && !is_pred) { a.g_poc[j] = a.poc[src]; a.g_qp[j] = a.qp[src]; }
+}
+
+__global__ __launch_bounds__(256) void guard_scatter_kernel(const GuardScatterArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x, j = t / (a.n_logits + 1), e = t - j * (a.n_logits + 1);
+  if (j >= a.k) return;
+  const int dst = a.idx[j];
+  if (e == a.n_logits) a.split[dst] = a.g_split[j];
+  else if (a.logits) a.logits[(size_t)dst * a.n_logits + e] = a.g_logits[(size_t)j * a.n_logits + e];
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which device ordinals a kernel has been
+// configured on (a process may hold contexts on several GPUs; concurrent first launches at worst set it twice).
+struct DeviceOnce {
+  std::atomic<uint64_t> mask[4] = {};
+  bool need(int *dev) const {
+    if (hipGetDevice(dev) != hipSuccess) *dev = 0;
+    return !(mask[(*dev >> 6) & 3].load(std::memory_order_acquire) & (1ull << (*dev & 63)));
+  }
+  void done(int dev) { mask[(dev >> 6) & 3].fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
+template <class K> static hipError_t ensure_big_lds(K kern, DeviceOnce &once) {
+  int dev = 0;
+  if (!once.need(&dev)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) once.done(dev);
+  return e;
+}
 template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
   auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA, CBP>;
@@ -1900,12 +2008,8 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
   const int patch_lds = (DMA ? 2 : NSPLIT) * a.patch_bytes;
   const int lds = patch_lds + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   dim3 grid(grid_x, COUT / (32 * CBT));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_C * WAVES_P), lds, st, a);
@@ -1918,12 +2022,8 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
   constexpr int CBT = WCB * WAVES_C, NW = WAVES_C * WAVES_P;
   constexpr int NWP = NWL ? NWL - NWL / 2 : NW - NW / 2;
   const int lds = 2 * a.patch_bytes + RB * GT * (KC / 16) * CBT * 1024 + (NWL ? 32 * CBT * 4 * (SC ? 2 : 1) : 0);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   if (lds > 160 * 1024 || (a.patch_bytes >> 10) > UNP * NWP) return hipErrorInvalidValue;
   dim3 grid(grid_x, COUT / (32 * CBT));
   hipLaunchKernelGGL(kern, grid, dim3(64 * (NW + NWL)), lds, st, a);
@@ -2191,12 +2291,8 @@ hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds,
 
 hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) {
   constexpr int lds = (20 * 36 + 18 * 34) * 80 + 2 * 18 * 1024;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)block32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(block32_kernel, once); e != hipSuccess) return e;
   hipLaunchKernelGGL(block32_kernel, dim3(grid_x), dim3(512), lds, st, a);
   return hipGetLastError();
 }
@@ -2209,5 +2305,27 @@ hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t
 
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st) {
   hipLaunchKernelGGL(heads_kernel, dim3(n), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_flat_stat(const FlatStatArgs &a, bool aligned8, hipStream_t st) {
+  if (aligned8) hipLaunchKernelGGL(flat_stat_kernel<true>, dim3(a.n), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flat_stat_kernel<false>, dim3(a.n), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_guard_select(const GuardSelectArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(guard_select_kernel, dim3(1), dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_guard_gather(const GuardGatherArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(guard_gather_kernel, dim3(a.k, 2), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_guard_scatter(const GuardScatterArgs &a, hipStream_t st) {
+  const int items = a.k * (a.n_logits + 1);
+  hipLaunchKernelGGL(guard_scatter_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -35,6 +35,7 @@ class SplitPredictor {
     cfg.max_batch = 1;
     cfg.flags = flags;
     cfg.guard_margin = 0.f;  // default threshold when MLT_FLAG_DECISION_GUARD is set
+    cfg.tolerance = 0.f;     // default |dlogit| contract (1e-3) for the load-time calibration of the fast arithmetic
     m_mask = sizeMask ? sizeMask : MLT_SIZE_128;
     const int rc = mlt_init(&cfg, &m_ctx);
     if (rc != MLT_OK) {

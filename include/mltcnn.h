@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MLT_ABI_VERSION 1
+#define MLT_ABI_VERSION 2
 
 enum {
   MLT_OK = 0,
@@ -42,18 +42,23 @@ enum {
 #define MLT_MAX_LOGITS 15 /* CU model: 2+3+4+6; CTU (128) model: 2+3+4 = 9 */
 
 /* mlt_config.flags -- arithmetic of the conv stack (DESIGN.md "Numerics").
- * fast : fp16 operands on the MFMA units, fp32 accumulate; |dlogit| ~ 5e-4 on ordinary inputs.
+ * fast : fp16 operands on the MFMA units, fp32 accumulate.  Its logit error depends on the weight set (rms 1.4e-4 ... 5.5e-4
+ *        over seeded weight sets, tails ~4.5x rms) and on the content (exactly-constant areas carry coherent rounding errors).
  * exact: every weight / activation is an fp16 (hi, lo) pair, 3 MFMA passes, ~fp32 accuracy (|dlogit| ~ 1e-5).
- * Defaults: 128x128 -> fast (it is the throughput path), 64/32/16 -> exact (few pixels per map, so
- * fp16 rounding is not averaged away by the global pooling, and these models are 5-65x cheaper). */
+ * Defaults: 128x128 -> fast WHEN the load-time calibration says the weight set meets mlt_config.tolerance with it (else
+ * exact), 64/32/16 -> exact (few pixels per map, so fp16 rounding is not averaged away by the global pooling, and these
+ * models are 5-65x cheaper).  Sizes that run the fast arithmetic are protected by two device-side guards, applied on
+ * EVERY entry point (single, batch, device-pointer, deferred):
+ *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are exactly constant in both input planes
+ *                            are re-evaluated with the exact arithmetic (their fp16 rounding errors are coherent);
+ *   decision guard (opt-in): CUs whose decision-head top-2 margin is below guard_margin are re-evaluated too, so the
+ *                            split mode handed to EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
+ * Both cost a second (exact) copy of the weights on the device (11 MB). */
 #define MLT_FLAG_EXACT_128 0x1u
 #define MLT_FLAG_FAST_SMALL 0x2u
-/* Decision guard for sizes running the fast arithmetic: mlt_predict / mlt_predict_batch (host-pointer entry points)
- * re-evaluate with the exact arithmetic every CU whose decision-head top-2 logit margin is below
- * mlt_config.guard_margin and return the exact logits / split for it.  The split mode handed to
- * EncModeCtrl::setNewModeList is then the one ~fp32 arithmetic gives, at fast throughput for all other CUs.
- * Costs a second (exact) copy of the weights on the device. */
 #define MLT_FLAG_DECISION_GUARD 0x4u
+#define MLT_FLAG_NO_FLAT_GUARD 0x8u    /* fast arithmetic without the flat-content guard (measurement only) */
+#define MLT_FLAG_NO_CALIBRATION 0x10u  /* keep the fast arithmetic whatever the weight set (measurement only) */
 
 typedef struct mlt_ctx mlt_ctx;
 
@@ -68,8 +73,10 @@ typedef struct mlt_config {
                              element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
   int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
   uint32_t flags;         /* MLT_FLAG_* bits, 0 = defaults */
-  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 0.02
-                             (about 7x the largest fast-mode logit error measured on the degenerate fixtures) */
+  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 0.02 */
+  float tolerance;        /* |dlogit| contract the fast arithmetic is calibrated against at load time; <= 0 => 1e-3
+                             (BASELINE.json north_star) */
+  uint32_t reserved;      /* 0 */
 } mlt_config;
 
 /* Create a context: selects the device, allocates workspaces, loads + folds + packs weights
@@ -78,8 +85,21 @@ typedef struct mlt_config {
 int mlt_init(const mlt_config *cfg, mlt_ctx **out);
 
 /* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
- * blob arrives over RCCL broadcast instead of from weights_dir. */
+ * blob arrives over RCCL broadcast instead of from weights_dir.  A size configured for the fast arithmetic is
+ * CALIBRATED here: 48 seeded synthetic CUs run through the fast and the exact arithmetic on the device; the fast
+ * arithmetic is kept only if 5.5 x rms|dlogit| <= tolerance and max|dlogit| <= 0.75 x tolerance, otherwise the size
+ * runs exact (mlt_arithmetic reports the outcome). */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
+
+/* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
+typedef struct mlt_arith_info {
+  int32_t exact;          /* 1: (hi, lo) pairs, 0: fast */
+  int32_t calibrated;     /* 1: the calibration ran for this size */
+  float calib_rms, calib_max; /* |dlogit| fast vs exact over the calibration CUs */
+  int32_t flat_guard, decision_guard;
+  uint64_t guard_reruns;  /* CUs re-evaluated by the guards since init */
+} mlt_arith_info;
+int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 
 /* Replaces EncCu.cpp:806-921 for ONE CU: gathers size x size luma from the original and the
  * prediction buffers (Pel = int16, element strides as AreaBuf exposes them, Buffer.h:94-105),
@@ -95,8 +115,10 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
 int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred,
                       const int32_t *poc, const int32_t *qp, int32_t *split_mode, float *logits);
 
-/* Same with every pointer in DEVICE memory; enqueues on the context's stream and returns
- * without synchronising (call mlt_synchronize).  This is the HBM-resident path bench.py times. */
+/* Same with every pointer in DEVICE memory; enqueues on the context's stream; call mlt_synchronize before reading the
+ * results.  With a guard active for `size` the call waits for each chunk's fast pass to read back the NUMBER of flagged
+ * CUs (4 bytes) and enqueues their exact re-evaluation; without guards it never synchronises.  This is the
+ * HBM-resident path bench.py times. */
 int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, const void *d_pred,
                              const void *d_poc, const void *d_qp, void *d_split_mode, void *d_logits);
 
@@ -107,7 +129,7 @@ int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, c
  * can postpone EncModeCtrl::setNewModeList for k independent CUs (CTUs of a wavefront, EncCu.cpp:792-800) pays one
  * ~0.2 ms launch for all k instead of k synchronous calls.  Up to MLT_DEFER_CAP CUs per batch (a full batch is flushed
  * by the next submit); a ticket stays valid until two further batches of its size have been started.  Results are
- * bit-identical to mlt_predict (the decision guard is not applied on this path). */
+ * bit-identical to mlt_predict (guards included: flagged CUs of a batch are re-evaluated by its first mlt_wait). */
 #define MLT_DEFER_CAP 64
 typedef uint64_t mlt_ticket;
 int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride,

@@ -18,21 +18,23 @@ def lib(pkg):
 def test_exports_match_header(pkg, lib):
     header = open(os.path.join(ROOT, "include", "mltcnn.h")).read()
     declared = set(re.findall(r"\b(mlt_[a-z_0-9]+)\s*\(", header))
-    declared -= {"mlt_config", "mlt_ctx", "mlt_kernel_time"}
+    declared -= {"mlt_config", "mlt_ctx", "mlt_kernel_time", "mlt_arith_info"}
     assert declared == set(pkg.capi.EXPORTS), declared ^ set(pkg.capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in mltcnn.h but not exported"
 
 
 def test_abi_version_and_logit_counts(lib):
-    assert lib.mlt_abi_version() == 1
+    assert lib.mlt_abi_version() == 2
     assert [lib.mlt_num_logits(s) for s in (128, 64, 32, 16, 8)] == [9, 15, 15, 15, 0]
 
 
 def test_config_struct_layout(pkg):
     # must match `struct mlt_config` in include/mltcnn.h (x86-64 SysV)
-    assert C.sizeof(pkg.capi.MltConfig) == 48
+    assert C.sizeof(pkg.capi.MltConfig) == 56
     assert pkg.capi.MltConfig.guard_margin.offset == 44
+    assert pkg.capi.MltConfig.tolerance.offset == 48
+    assert C.sizeof(pkg.capi.MltArithInfo) == 32
     assert pkg.capi.MltConfig.weights_dir.offset == 8
     assert pkg.capi.MltConfig.head_index.offset == 20
     assert C.sizeof(pkg.capi.MltKernelTime) == 72

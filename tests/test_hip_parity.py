@@ -11,14 +11,11 @@ from helpers import SIZES, decisive, head_slices, load_golden, materialise, vari
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3  # north_star: logits within 1e-3 of the reference
-# The default arithmetic is "fast" (single fp16 pass) for 128x128 and "exact" (fp16 hi+lo pairs, 3 passes) for
-# 64/32/16 (DESIGN.md "Numerics").  Two fixtures are degenerate on purpose and are the only cases where the fast
-# path exceeds 1e-3 (measured 1.3e-3 and 2.7e-3): `saturated` (|org - pred| = 1023 on every pixel, ~50x an ordinary
-# residual, so every activation - and its fp16 ulp - is ~50x larger) and `flat` (a constant picture: every pixel
-# carries the SAME rounding error, so global average pooling averages nothing away).  They are held to
-# FAST_DEGENERATE_TOL in fast mode and to LOGIT_TOL in exact mode (test_golden_fixtures_128_exact_mode).
-FAST_DEGENERATE_TOL = 5e-3
-FAST_DEGENERATE = ("saturated", "flat")
+# Default arithmetic (DESIGN.md "Numerics"): 64/32/16 run "exact" (fp16 hi+lo pairs, 3 passes); 128 runs "fast" (single
+# fp16 pass) when the load-time calibration finds the weight set within tolerance, else exact, and CUs with large
+# exactly-constant areas (coherent fp16 rounding errors) are re-evaluated with the exact arithmetic by a device-side guard.
+# EVERY fixture is held to LOGIT_TOL in every shipped configuration; only the measurement-only configuration without guards
+# and calibration (test_golden_fixtures_128_raw_fast_arithmetic) documents what the raw single-pass arithmetic does.
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +39,9 @@ def _run_golden(pkg, size, flags, tol_of):
         split, logits = m.predict_batch(org, pred, poc, qp)
         err = float(np.abs(logits - exp).max())
         worst[case["name"]] = err
+        if size == 128:
+            a = m.arithmetic(size)
+            worst[case["name"] + ":arith"] = ("exact" if a["exact"] else "fast") + (f" calib rms {a['calib_rms']:.1e} max {a['calib_max']:.1e} reruns {a['guard_reruns']}" if a["calibrated"] else "")
         tol = tol_of(case["name"])
         assert err <= tol, f"{size}/{case['name']}: |dlogit| {err:.3e} > {tol:.0e}"
         dec = 2 if size == 128 else 0
@@ -50,12 +50,24 @@ def _run_golden(pkg, size, flags, tol_of):
             if decisive(exp[i], sl, 2 * tol):
                 assert split[i] == exp_arg[i][dec], (case["name"], i)
         m.close()
-    print(size, "flags", flags, {k: f"{v:.1e}" for k, v in worst.items()})
+    print(size, "flags", flags, {k: (f"{v:.1e}" if isinstance(v, float) else v) for k, v in worst.items()})
 
 
 @pytest.mark.parametrize("size", SIZES)
 def test_golden_fixtures_default_mode(gpu, size):
-    _run_golden(gpu, size, 0, lambda name: FAST_DEGENERATE_TOL if (size == 128 and name in FAST_DEGENERATE) else LOGIT_TOL)
+    _run_golden(gpu, size, 0, lambda name: LOGIT_TOL)
+
+
+def test_golden_fixtures_128_fast_arithmetic_with_guards(gpu):
+    """The configuration bench.py times with seed-10 weights, forced for EVERY fixture weight set (no calibration): single
+    fp16 pass + flat-content guard.  All 14 reference fixtures within 1e-3."""
+    _run_golden(gpu, 128, gpu.capi.FLAG_NO_CALIBRATION, lambda name: LOGIT_TOL)
+
+
+def test_golden_fixtures_128_raw_fast_arithmetic(gpu):
+    """Measurement only: no calibration, no guards.  Documents what the guards are for: the constant-picture fixture exceeds
+    1e-3 (1.3e-3 measured) because every pixel carries the same rounding error."""
+    _run_golden(gpu, 128, gpu.capi.FLAG_NO_CALIBRATION | gpu.capi.FLAG_NO_FLAT_GUARD, lambda name: 5e-3)
 
 
 def test_golden_fixtures_128_exact_mode(gpu):
@@ -144,38 +156,112 @@ def test_batch_split_invariance_and_determinism(gpu):
     m.close()
 
 
-def test_decision_guard_replaces_near_ties_with_exact_results(gpu):
-    """MLT_FLAG_DECISION_GUARD: CUs whose fast decision-head margin is under the threshold come back with the
-    exact-mode logits / split (bit-identical to an exact-mode context), all others keep the fast result."""
+def test_guards_replace_flagged_cus_with_exact_results_on_every_entry_point(gpu):
+    """Flat guard (default) + MLT_FLAG_DECISION_GUARD: CUs with >= 1/8 exactly-constant quads, and CUs whose fast decision-head
+    margin is under the threshold, come back with the exact-mode logits / split (bit-identical to an exact-mode context);
+    all others keep the fast result.  Same through mlt_predict, mlt_predict_batch, mlt_predict_batch_device and the
+    deferred API."""
+    import torch
     pkg = gpu
     size, n = 128, 40
+    NC = pkg.capi.FLAG_NO_CALIBRATION
     blob = pkg.weights.synthetic_blob(0, 21)
     org, pred = pkg.synth.make_patches(size, n, 17)
-    o2, p2 = pkg.synth.make_patches(size, 4, 18, pkg.synth.KIND_SATURATED)
-    org, pred = np.concatenate([org, o2]), np.concatenate([pred, p2])
-    n += 4
+    o2, p2 = pkg.synth.make_patches(size, 2, 18, pkg.synth.KIND_SATURATED)   # 4x4 checkerboard: every aligned quad is constant
+    o3, p3 = pkg.synth.make_patches(size, 2, 19, pkg.synth.KIND_FLAT)
+    o4, p4 = pkg.synth.make_patches(size, 2, 20)
+    o4[:, :24, :] = o3[:, :24, :]; p4[:, :24, :] = p3[:, :24, :]            # 24 of 128 rows constant: 18.75 % of the quads
+    o5, p5 = pkg.synth.make_patches(size, 2, 21)
+    o5[:, :8, :] = o3[:, :8, :]; p5[:, :8, :] = p3[:, :8, :]                # 6.25 %: below the threshold, stays fast
+    org, pred = np.concatenate([org, o2, o3, o4, o5]), np.concatenate([pred, p2, p3, p4, p5])
+    flat_flag = np.zeros(n + 8, bool)
+    flat_flag[n:n + 6] = True
+    n += 8
     poc, qp = pkg.synth.make_scalars(n, 17)
-    fast, exact = _ctx(pkg, size, blob), _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
+    raw = _ctx(pkg, size, blob, flags=NC | pkg.capi.FLAG_NO_FLAT_GUARD)
+    fast = _ctx(pkg, size, blob, flags=NC)
+    exact = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
+    s_r, l_r = raw.predict_batch(org, pred, poc, qp)
     s_f, l_f = fast.predict_batch(org, pred, poc, qp)
     s_e, l_e = exact.predict_batch(org, pred, poc, qp)
+    assert fast.arithmetic(size)["exact"] == 0 and fast.arithmetic(size)["guard_reruns"] == 6
+    assert np.array_equal(l_f[flat_flag], l_e[flat_flag]) and np.array_equal(s_f[flat_flag], s_e[flat_flag])
+    assert np.array_equal(l_f[~flat_flag], l_r[~flat_flag]) and np.array_equal(s_f[~flat_flag], s_r[~flat_flag])
+    assert not np.array_equal(l_r[flat_flag], l_e[flat_flag])
     head = slice(5, 9)  # CTU model decision head = element [2] (EncCu.cpp:913-915)
-    top2 = np.sort(l_f[:, head], axis=1)
+    top2 = np.sort(l_r[:, head], axis=1)
     margins = top2[:, -1] - top2[:, -2]
     thr = float(np.median(margins))
-    flagged = margins < np.float32(thr)
-    assert 0 < flagged.sum() < n
-    g = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_DECISION_GUARD, guard_margin=thr)
+    flagged = (margins < np.float32(thr)) | flat_flag
+    assert flat_flag.sum() < flagged.sum() < n
+    g = _ctx(pkg, size, blob, flags=NC | pkg.capi.FLAG_DECISION_GUARD, guard_margin=thr)
     s_g, l_g = g.predict_batch(org, pred, poc, qp)
     assert np.array_equal(l_g[flagged], l_e[flagged]) and np.array_equal(s_g[flagged], s_e[flagged])
-    assert np.array_equal(l_g[~flagged], l_f[~flagged]) and np.array_equal(s_g[~flagged], s_f[~flagged])
+    assert np.array_equal(l_g[~flagged], l_r[~flagged]) and np.array_equal(s_g[~flagged], s_r[~flagged])
     s_only, none = g.predict_batch(org, pred, poc, qp, want_logits=False)
     assert none is None and np.array_equal(s_only, s_g)
-    for i in (int(np.flatnonzero(flagged)[0]), int(np.flatnonzero(~flagged)[0])):  # EncCu call-site entry point
+    # device-pointer entry (ragged chunks so that flagged CUs fall into several chunks)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+    d_split = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    d_lg = torch.zeros((n, 9), dtype=torch.float32, device=dev)
+    g.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_lg.data_ptr())
+    g.synchronize()
+    assert np.array_equal(d_lg.cpu().numpy(), l_g) and np.array_equal(d_split.cpu().numpy(), s_g)
+    d_split.fill_(-1)
+    g.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), None)
+    g.synchronize()
+    assert np.array_equal(d_split.cpu().numpy(), s_g)
+    # EncCu call-site entry point and the deferred API
+    picks = [int(np.flatnonzero(flagged & ~flat_flag)[0]), int(np.flatnonzero(~flagged)[0]), int(np.flatnonzero(flat_flag)[0]), n - 5]
+    for i in picks:
         for _ in range(2):  # second call replays the captured graph after the exact pass grew the workspace
             s1, l1 = g.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
-            assert s1 == s_g[i] and np.array_equal(l1, l_g[i])
-    for m in (fast, exact, g):
+            assert s1 == s_g[i] and np.array_equal(l1, l_g[i]), i
+    tickets = [g.submit(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(n)]
+    for i in (n - 1, 0, 41, 7, n - 3):
+        s1, l1 = g.wait(size, tickets[i])
+        assert s1 == s_g[i] and np.array_equal(l1, l_g[i]), i
+    for m in (raw, fast, exact, g):
         m.close()
+
+
+def test_load_time_calibration_picks_the_arithmetic(gpu):
+    """mlt_load_weights measures fast vs exact on 48 seeded CUs: the bench weight set (seed 10) keeps the fast arithmetic, a
+    weight set whose fp16 error is ~4x larger (seed 22: emulated rms 5.5e-4) is switched to exact, and a tight tolerance
+    switches any set.  Reloading other weights into the same context re-calibrates and invalidates the captured graph."""
+    import oracle
+    pkg = gpu
+    size = 128
+    org, pred = pkg.synth.make_patches(size, 4, 5)
+    poc, qp = pkg.synth.make_scalars(4, 5)
+    b10, b22 = pkg.weights.synthetic_blob(0, 10), pkg.weights.synthetic_blob(0, 22)
+    m = _ctx(pkg, size, b10)
+    a = m.arithmetic(size)
+    print("seed 10:", a)
+    assert a["calibrated"] == 1 and a["exact"] == 0 and 0 < a["calib_rms"] < 1.8e-4 and a["flat_guard"] == 1
+    s10 = [m.predict(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(4)]  # captures the graph with seed-10 weights
+    m.load_weights(size, b22)                                                      # frees them: the graph must not survive
+    a = m.arithmetic(size)
+    print("seed 22:", a)
+    assert a["calibrated"] == 1 and a["exact"] == 1 and a["calib_rms"] > 1.8e-4 and a["flat_guard"] == 0
+    fresh = _ctx(pkg, size, b22)
+    ref, ref_split = oracle.Oracle(b22).forward(org, pred, poc, qp)
+    for i in range(4):
+        s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        s2, l2 = fresh.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        assert s1 == s2 and np.array_equal(l1, l2), "reloaded context differs from a fresh one"
+        assert np.abs(l1 - ref[i]).max() <= 1e-4
+        assert not np.array_equal(l1, s10[i][1])
+    m.load_weights(size, b10)
+    assert m.arithmetic(size)["exact"] == 0
+    for i in range(4):
+        s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        assert s1 == s10[i][0] and np.array_equal(l1, s10[i][1])
+    tight = _ctx(pkg, size, b10, tolerance=2e-4)
+    assert tight.arithmetic(size)["exact"] == 1
+    for c in (m, fresh, tight):
+        c.close()
 
 
 def test_repeated_runs_bit_identical_128(gpu):
@@ -186,7 +272,7 @@ def test_repeated_runs_bit_identical_128(gpu):
     blob = pkg.weights.synthetic_blob(0, 12)
     org, pred = pkg.synth.make_patches_bulk(size, n, 9)
     poc, qp = pkg.synth.make_scalars(n, 9)
-    m = _ctx(pkg, size, blob)
+    m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)  # the fast kernels are the ones under test
     s0, l0 = m.predict_batch(org, pred, poc, qp)
     assert np.isfinite(l0).all()
     for _ in range(6):
@@ -259,7 +345,7 @@ def test_kernel_variant_switches_do_not_change_results(gpu):
     nmax = 258
     org, pred = pkg.synth.make_patches_bulk(size, nmax, 41)
     poc, qp = pkg.synth.make_scalars(nmax, 41)
-    m = _ctx(pkg, size, blob)
+    m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)  # the fast kernels are the ones under test
     s8, l8 = m.predict_batch(org[:8], pred[:8], poc[:8], qp[:8])
     ref, ref_split = oracle.Oracle(blob).forward(org[:8], pred[:8], poc[:8], qp[:8])
     assert np.abs(l8 - ref).max() <= LOGIT_TOL and np.array_equal(s8, ref_split)
@@ -329,19 +415,22 @@ def test_cpp_call_site_demo_matches_python_binding(gpu, tmp_path):
     assert np.allclose(got, logits[5:9], atol=2e-4), (got, logits[5:9])
 
 
-def test_full_batch_4096_properties(gpu):
-    """BASELINE.json's full size (4096 x 128x128): size-independent properties, all bit-exact --
-    (1) run-to-run determinism, (2) permutation equivariance (a CU's result does not depend on its batch position or
-    neighbours), (3) invariance to the internal chunking, (4) device-pointer entry == host-pointer entry --
-    plus a random 24-CU spot check of that same batch against the oracle."""
+@pytest.mark.parametrize("size", SIZES)
+def test_full_batch_4096_properties(gpu, size):
+    """BASELINE.json's full sizes (configs[1]: 4096 x 128x128, configs[2]: 4096 x 64 / 32 / 16): size-independent properties,
+    all bit-exact -- (1) run-to-run determinism, (2) permutation equivariance (a CU's result does not depend on its batch
+    position or neighbours), (3) invariance to the internal chunking (ragged MLT_CHUNK), (4) device-pointer entry ==
+    host-pointer entry -- plus a random 24-CU spot check of that same batch against the oracle."""
     import os
     import torch
     from oracle import Oracle
     pkg = gpu
-    n, size = 4096, 128
-    blob = pkg.weights.synthetic_blob(0, 10)
+    n = 4096
+    arch = pkg.synth.arch_for_size(size)
+    blob = pkg.weights.synthetic_blob(arch, 10)
     org, pred = pkg.synth.make_patches_bulk(size, n, 0xBEEF)
     poc, qp = pkg.synth.make_scalars(n, 0xBEEF)
+    nl = sum(pkg.synth.HEAD_CLASSES[arch])
     m = _ctx(pkg, size, blob)
     s0, l0 = m.predict_batch(org, pred, poc, qp)
     s1, l1 = m.predict_batch(org, pred, poc, qp)
@@ -353,7 +442,7 @@ def test_full_batch_4096_properties(gpu):
     dev = torch.device("cuda", 0)
     d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
     d_split = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    d_logits = torch.zeros((n, 9), dtype=torch.float32, device=dev)
+    d_logits = torch.zeros((n, nl), dtype=torch.float32, device=dev)
     m.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_logits.data_ptr())
     m.synchronize()
     assert np.array_equal(d_logits.cpu().numpy(), l0) and np.array_equal(d_split.cpu().numpy(), s0)
@@ -362,19 +451,64 @@ def test_full_batch_4096_properties(gpu):
     try:
         mc = _ctx(pkg, size, blob)
         sc, lc = mc.predict_batch(org, pred, poc, qp)
+        d_split.fill_(-1)
+        mc.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_logits.data_ptr())
+        mc.synchronize()
         mc.close()
     finally:
         del os.environ["MLT_CHUNK"]
     assert np.array_equal(lc, l0) and np.array_equal(sc, s0), "result depends on chunking"
+    assert np.array_equal(d_logits.cpu().numpy(), l0) and np.array_equal(d_split.cpu().numpy(), s0), "device entry depends on chunking"
     idx = np.sort(np.random.RandomState(11).choice(n, 24, replace=False))
     ref, ref_split = Oracle(blob).forward(org[idx], pred[idx], poc[idx], qp[idx], threads=8)
     err = float(np.abs(l0[idx] - ref).max())
-    print("full batch: max|dlogit| on 24 random CUs", err)
+    print(size, "full batch: max|dlogit| on 24 random CUs", err)
     assert err <= LOGIT_TOL
-    sl = head_slices([2, 3, 4])[2]
+    sl = head_slices(pkg.synth.HEAD_CLASSES[arch])[2 if size == 128 else 0]
     for k, i in enumerate(idx):
         if decisive(ref[k], sl, 2 * LOGIT_TOL):
             assert s0[i] == ref_split[k]
+
+
+def test_two_host_threads_two_contexts(gpu):
+    """SURVEY 8b threading contract: one context per EncCu thread, mlt_init thread-safe.  Two host threads create their own
+    contexts concurrently (different CU sizes and weight sets) and interleave mlt_predict / mlt_predict_batch calls; every
+    result equals the single-threaded one."""
+    import threading
+    pkg = gpu
+    jobs = {}
+    for t, (size, seed) in enumerate(((128, 10), (32, 7))):
+        blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), seed)
+        org, pred = pkg.synth.make_patches_bulk(size, 24, 60 + t)
+        poc, qp = pkg.synth.make_scalars(24, 60 + t)
+        m = _ctx(pkg, size, blob)
+        jobs[t] = dict(size=size, blob=blob, data=(org, pred, poc, qp), want=m.predict_batch(org, pred, poc, qp))
+        m.close()
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            j = jobs[t]
+            org, pred, poc, qp = j["data"]
+            start.wait()
+            m = _ctx(pkg, j["size"], j["blob"])  # concurrent mlt_init + weight load + calibration
+            for rnd in range(6):
+                for i in range(0, 24, 5):
+                    s, l = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+                    assert s == j["want"][0][i] and np.array_equal(l, j["want"][1][i]), (t, rnd, i)
+                s, l = m.predict_batch(org, pred, poc, qp)
+                assert np.array_equal(s, j["want"][0]) and np.array_equal(l, j["want"][1]), (t, rnd)
+            m.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in jobs]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errors, errors
 
 
 def test_empty_and_single_batches(gpu):
@@ -478,22 +612,29 @@ def test_one_context_serving_all_four_cu_sizes(gpu):
 
 
 def test_bench_contract_two_ranks_on_one_gpu(gpu):
-    """bench.py under torch.distributed.run with two ranks (sharing the GPU, gloo for the init-time collectives): rank 0
-    prints exactly one JSON line carrying the contract keys, n_gpus = 2, and parity-clean results."""
+    """Plain `python bench.py --gpus 2` (no torchrun in the command: bench.py starts its own ranks as a child process) with
+    the two ranks sharing the one GPU of this box (gloo for the init-time collectives): rank 0 prints exactly one JSON line
+    carrying the contract keys, n_gpus = 2, and parity-clean results over the checked CUs."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MLT_BENCH_OVERSUBSCRIBE="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256"],
-                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "parity", "rccl"):
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["value"] > 0
+    assert d["rccl"]["world"] == 2 and len(d["rccl"]["devices"]) == 2 and d["rccl"]["backend"] == "gloo"  # nccl (RCCL) when ranks <= GPUs
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
-    assert d["parity"]["max_abs_dlogit"] <= LOGIT_TOL and d["parity"]["split_identical"]
+    assert d["parity"]["max_abs_dlogit"] <= LOGIT_TOL and d["parity"]["split_mismatch_decisive"] == 0
+    # without the oversubscription switch two ranks on a one-GPU box must fail loudly instead of measuring one GPU twice
+    env.pop("MLT_BENCH_OVERSUBSCRIBE")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
