@@ -38,3 +38,52 @@ def test_cpp_host_mirror_builds_and_links(pkg, tmp_path):
     assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib"))
     assert out.returncode == 0 and "abi 2, logits(128) 9, logits(32) 15" in out.stdout
+
+
+def test_gate_truth_table_matches_the_reference_condition(pkg, tmp_path):
+    """SplitPredictor::gate against EncCu.cpp:746-756 (useCNN): luma / joint tree only, never on I slices, square CUs of an
+    enabled size only (reference: 128; the 64 / 32 / 16 clauses are commented out at :754), CU entirely inside the picture."""
+    lib = pkg.build.build_lib()
+    src = tmp_path / "gate_table.cpp"
+    src.write_text(r'''
+#include "mlt_split_predictor.hpp"
+int main(int argc, char **argv) {
+  unsigned mask = (unsigned)std::strtoul(argv[1], nullptr, 0);
+  mlt::SplitPredictor cnn("/nonexistent", 0, mask);   // no GPU / no weights here: gate() is pure host logic
+  const int picW = 1920, picH = 1080;
+  const int sizes[] = {128, 64, 32, 16, 8};
+  for (int chType = 0; chType < 2; ++chType)
+    for (int intra = 0; intra < 2; ++intra)
+      for (int w : sizes)
+        for (int h : sizes)
+          for (int x : {0, 1792, 1856, 1900})
+            for (int y : {0, 896, 960, 1024, 1072})
+              std::printf("%d %d %d %d %d %d %d\n", chType, intra, w, h, x, y, (int)cnn.gate(chType, intra != 0, x, y, w, h, picW, picH));
+  return 0;
+}
+''')
+    exe = str(tmp_path / "gate_table")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "host"), str(src), "-o", exe,
+           "-L" + os.path.dirname(lib), "-lmltcnn_hip", "-Wl,-rpath," + os.path.dirname(lib)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def reference_use_cnn(chType, intra, cuw, cuh, cux, cuy, enabled, picW=1920, picH=1080):
+        use = False
+        if chType == 0 and not intra:                                   # EncCu.cpp:753
+            if cuw == cuh and cuw in enabled:                           # :754 (128 only upstream)
+                if cux + cuw <= picW and cuy + cuh <= picH:             # :755
+                    use = True
+        return use
+
+    for mask, enabled in ((0x1, {128}), (0x0, {128}), (0xF, {128, 64, 32, 16}), (0x6, {64, 32})):
+        out = subprocess.run([exe, str(mask)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib"))
+        assert out.returncode == 0
+        rows = [tuple(map(int, l.split())) for l in out.stdout.splitlines() if l and l[0].isdigit()]
+        assert len(rows) == 2 * 2 * 5 * 5 * 4 * 5
+        positives = 0
+        for chType, intra, w, h, x, y, got in rows:
+            want = reference_use_cnn(chType, bool(intra), w, h, x, y, enabled)
+            assert bool(got) == want, (mask, chType, intra, w, h, x, y)
+            positives += want
+        assert positives > 0

@@ -33,8 +33,10 @@ def main():
     else:
         import torch
         src = args.paths[0]
+        # `.pth` = {'params': state_dict} of plain tensors: weights_only=True never unpickles arbitrary objects from a
+        # third-party checkpoint.  A TorchScript archive (model2torchScript.py:46-48) is refused by it and goes to jit.load.
         try:
-            obj = torch.load(src, map_location="cpu", weights_only=False)
+            obj = torch.load(src, map_location="cpu", weights_only=True)
         except Exception:
             obj = torch.jit.load(src, map_location="cpu")
         if hasattr(obj, "state_dict"):
