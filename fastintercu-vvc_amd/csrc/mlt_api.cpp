@@ -390,6 +390,36 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
 
+// BasicBlock tail of a stage as ONE launch (chain_kernel): b0 = relu(bn2(conv2 t) + sc); t1 = relu(bn1(conv1 b0));
+// out = relu(bn2(conv2 t1) + b0) (+ GAP).  Fast arithmetic, stages whose whole sample fits the LDS (128 channels @ 16 x 16).
+int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap) {
+  const int c = B0.conv2.cout;
+  ChainArgs a{};
+  a.x = t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n;
+  const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
+  for (int k = 0; k < 3; ++k) {
+    a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
+  }
+  a.cv[0].res_mode = 1; a.cv[0].res = sc; a.cv[0].save = 1; a.cv[2].res_mode = 2;
+  const int hw = h * h;
+  a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
+  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int grid_x = n > wg_cap ? wg_cap : n;  // one sample per workgroup, one workgroup per CU (its LDS is full), persistent
+  char name[48];
+  std::snprintf(name, sizeof name, "chain3_s1_%d_h%d(conv2+conv1+conv2)", c, h);
+  const double px = (double)n * hw;
+  const double flops = 3.0 * 2.0 * px * c * c * 9;
+  const double bytes = px * c * 2 * (2 + (y ? 1 : 0)) + 3.0 * (double)B0.conv2.w.size() * 2;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin(name, flops, bytes, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_chain(c, h, a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
+  return MLT_OK;
+}
+
 // One chunk of n CUs through the whole network, everything on ctx->stream.
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
@@ -441,6 +471,17 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         hout = ho;
         if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+      if (s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], hout) && B0.conv2.taps == 9 && B0.conv2.kc == 64 && B0.conv2.ct == m.planes[s] &&
+          B0.conv2.gt == 3) {  // rest of the stage in one launch: activations stay in LDS, b0 in registers
+        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s]))) return rc;
+        cur = outs[s];
+        h = hout;
+        const int hd = s - 1;
+        ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
+        ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
+        continue;
+      }
       io = ConvIO();
       io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
       io.x_lo = io.y_lo = io.res_lo = lo_st;

@@ -66,6 +66,30 @@ struct StemBlockArgs {
   int n, hout_l, ntiles;       // H = 1 << hout_l (>= 32), picture 2H x 2H; tiles of 16 x 32 output pixels
 };
 
+// Fused chain of stride-1 3x3 convs on whole samples (chain_kernel): the BasicBlock tail of a stage,
+//   b0 = relu(bn2(conv2(t)) + sc) ; t1 = relu(bn1(conv1(b0))) ; out = relu(bn2(conv2(t1)) + b0)      (arch:52-57)
+// with every intermediate kept on chip (activations in LDS, b0 as the residual in registers).
+struct ChainConv {
+  const void *w;       // packed fp16 weights (same packing as the stand-alone conv of this layer)
+  const float *bias;   // folded BN bias
+  float acc_scale;
+  int relu;
+  int res_mode;        // 0 none, 1 from `res` (HBM, same layout as the output), 2 from the tile saved by an earlier conv
+  int save;            // 1: keep this conv's activated output tile in registers as a later conv's residual
+  const void *res;
+};
+struct ChainArgs {
+  const void *x;       // [n][H][H][C] fp16: input of the first conv
+  ChainConv cv[3];
+  int nconv;           // 2 or 3
+  void *y;             // [n][H][H][C] fp16 output of the last conv, or NULL (only the GAP sums are needed)
+  float *gap;          // fp32 GAP partial sums of the last conv's output [n][gap_slots][C], or NULL
+  int gap_slots, gap_l;
+  int n;
+};
+hipError_t mlt_launch_chain(int c, int h, const ChainArgs &a, int grid_x, hipStream_t st);
+bool mlt_chain_supported(int c, int h);
+
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)
   int slots[MLT_MAX_HEADS_K];

@@ -1269,6 +1269,285 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused chain of stride-1 3x3 convs on WHOLE samples (the BasicBlock tail of the 128@16 stage, arch:52-57):
+//     b0 = relu(bn2(conv2(t)) + sc) ;  t1 = relu(bn1(conv1(b0))) ;  out = relu(bn2(conv2(t1)) + b0)  (+ GAP, arch:288)
+// One 16-wave workgroup owns one sample: the 16 x 16 x 128 activation (64 KiB fp16) lives in LDS for the whole chain,
+// every conv reads it from there and its epilogue writes the next activation back IN PLACE (all waves have passed the
+// last weight step's barrier, so nobody reads the buffer any more); b0 -- the residual of the last conv -- stays in the
+// registers of the wave that produced it (a wave's output tile covers the same pixels x channels in every conv).  HBM
+// sees t and sc in, out (or only the GAP sums) out: no intermediate is written or re-read, no patch is staged per
+// conv, and three launches become one.
+//   * no halo: a tile is a whole sample, so a tap that leaves the map is conv padding.  The lane reads its own pixel
+//     instead and the fragment is ANDed with an all-zero mask (4 VALU ops per MFMA pair, hidden in the MFMA gaps);
+//     the buffer is unpadded, 16-byte channel slots XOR-swizzled with the pixel index (conflict-free ds_read_b128 for
+//     16 consecutive pixels, as in the LDS-DMA kernels above);
+//   * weights stream through the same LDS-DMA ring as conv_ring_dma_kernel (first half of the waves), continuously
+//     across convs and samples; 64 KiB activation + 2 x 48 KiB ring = the whole 160 KiB;
+//   * the next sample's input is fetched by LDS-DMA (second half of the waves) into each 64-channel region of the buffer
+//     as soon as the LAST conv has finished reading it: region c during chunk c+1, the last region during the final
+//     epilogue and the next sample's first chunk.
+// Bit-identical to the three stand-alone launches (same k order, same rounding points: fp16 activations between convs).
+// ---------------------------------------------------------------------------------------------
+template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV>
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
+  constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = TAPS / GT;
+  constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NW = WAVES_C * WAVES_P;
+  constexpr int H = 1 << HL, HW = H * H, M = HW << SPW_L;
+  static_assert(CT == C && M == 32 * WAVES_P * WPB && TAPS % GT == 0 && HW >= 32 && C % KC == 0, "tiling");
+  constexpr int WCHUNK = GT * KS * CBT * 1024, NPIECE = WCHUNK / 1024, NBUF = RB, PFD = RB - 1;
+  constexpr int NWR = NW / 2, NWP = NW - NWR, PPWR = (NPIECE + NWR - 1) / NWR;
+  constexpr int REGION = M * KC * 2, ACT = NCHUNK * REGION, RPIECE = REGION / 1024, PPR = (RPIECE + NWP - 1) / NWP;
+  static_assert(ACT + NBUF * WCHUNK <= 160 * 1024, "LDS");
+  static_assert(RB == 2 || RB == 3, "ring depth");
+  static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
+  static_assert(((GT * KS - 1) * CBT + WCB - 1) * 1024 < 65536, "fragment offsets are ds_read immediates");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *ring = smem + ACT;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+  const int p = lane & 31, h = lane >> 5;
+  const bool ring_wave = wave < NWR, patch_wave = !ring_wave;
+  const int lane16 = lane * 16;
+
+  // lane -> pixels (lane ranking: every 16-lane ds_read_b128 group owns 16 consecutive pixels, see conv_mfma_kernel)
+  const int pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
+  int mj[WPB];  // pixel index inside the tile = its LDS pixel slot; packs (sample, y, x)
+#pragma unroll
+  for (int j = 0; j < WPB; ++j) mj[j] = (wp * WPB + j) * 32 + pr;
+
+  const int ntiles = (a.n + (1 << SPW_L) - 1) >> SPW_L;
+  int t = blockIdx.x;
+  const int tstep = gridDim.x;
+  if (t >= ntiles) return;
+
+  // ---- weight ring: one global step sequence (sample, conv, chunk, tap group) ----
+  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCONV * NCHUNK * NG;
+  int r_cv = 0, r_ci = 0, r_gi = 0, slot_wr = 0, ahead = 0;
+  auto issue_ring = [&]() {
+    if (steps_to_issue <= 0) return;
+    if (ring_wave) {
+      const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
+      const char *src = wsrc + (size_t)(r_ci * TAPS + r_gi * GT) * (KS * CBT * 1024);
+      char *dst = ring + slot_wr * WCHUNK;
+#pragma unroll
+      for (int k = 0; k < PPWR; ++k) {
+        int pi = wave + k * NWR;
+        pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
+        glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+      }
+    }
+    --steps_to_issue;
+    ++ahead;
+    if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_cv == NCONV) r_cv = 0; } }
+    if (++slot_wr == NBUF) slot_wr = 0;
+  };
+  // ---- activation regions (patch waves): item it = (pixel q, position pos) at byte it * 16 of the region holds channel slot
+  // pos ^ ((q >> 1) & 7) of that pixel ----
+  auto dma_region = [&](int tile, int c) {
+    if (!patch_wave) return;
+#pragma unroll
+    for (int k = 0; k < PPR; ++k) {
+      const int piece = (wave - NWR) + k * NWP;
+      if (piece >= RPIECE) break;  // wave-uniform
+      const int it = piece * 64 + lane, q = it / SLOTS, pos = it & (SLOTS - 1);
+      const int sl = pos ^ ((q >> 1) & (SLOTS - 1));
+      int n = (tile << SPW_L) + (q >> (2 * HL));
+      n = n < a.n ? n : a.n - 1;  // ragged last tile: a valid sample again (its outputs are masked)
+      const char *src = (const char *)a.x + (((size_t)n * HW + (q & (HW - 1))) * C + c * KC + sl * 8) * 2;
+      glds16(src, smem + c * REGION + piece * 1024);
+    }
+  };
+
+  // ---- prologue ----
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) dma_region(t, c);
+#pragma unroll
+  for (int d = 0; d < PFD; ++d) issue_ring();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  int slot_rd = 0;
+  uint4v keep[WCB][WPB][2];  // residual tile saved by an earlier conv of the chain (packed fp16, pair16 layout)
+#pragma unroll
+  for (int i = 0; i < WCB; ++i)
+#pragma unroll
+    for (int j = 0; j < WPB; ++j)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) keep[i][j][qq] = uint4v{0u, 0u, 0u, 0u};
+
+  for (; t < ntiles; t += tstep) {
+    // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(mj[j]));
+    const bool has_next = t + tstep < ntiles;
+    int opix[WPB], gidx[WPB];  // flattened (n, y, x) of this lane's output pixels, GAP partial-sum rows
+#pragma unroll
+    for (int j = 0; j < WPB; ++j) {
+      const int nn = (t << SPW_L) + (mj[j] >> (2 * HL));
+      const bool ok = nn < a.n;
+      opix[j] = ok ? nn * HW + (mj[j] & (HW - 1)) : -1;
+      gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
+    }
+
+    static_for<NCONV>([&](auto kc) {
+      constexpr int cvi = decltype(kc)::value;
+      constexpr bool last = cvi == NCONV - 1;
+      const ChainConv &cv = a.cv[cvi];
+      // the two chains there are (host: run_chain): NCONV == 3: conv2(+sc from HBM, saved) -> conv1 -> conv2(+saved tile);
+      // NCONV == 2: conv1 -> conv2(+x from HBM); every conv is followed by a ReLU
+      constexpr int RES = NCONV == 3 ? (cvi == 0 ? 1 : cvi == 2 ? 2 : 0) : (cvi == 1 ? 1 : 0);
+      constexpr bool SAVE = NCONV == 3 && cvi == 0;
+      float16v acc[WCB][WPB];
+#pragma unroll
+      for (int i = 0; i < WCB; ++i)
+#pragma unroll
+        for (int j = 0; j < WPB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      uint4v resv[WCB][WPB][2];
+
+#pragma unroll 1
+      for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        const uint32_t pl = lds0 + chunk * REGION;
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+          issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
+          // the last conv has finished reading region chunk-1: the next sample's input may land there
+          if (last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
+          if (RES == 1 && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
+#pragma unroll
+            for (int i = 0; i < WCB; ++i)
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) {
+                const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * C + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)cv.res + o + 16 * qq);
+              }
+          }
+          {
+            constexpr int NITEM = GT * KS, NR = WCB + WPB;
+            const uint32_t wb = lds0 + ACT + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
+            half8 fa[FD + 1][WCB], fb[FD + 1][WPB];
+            uint32_t rowa[WPB], hs[WPB], mcur[WPB], mvs[FD + 1][WPB];
+            auto issue = [&](auto ic) {
+              constexpr int item = decltype(ic)::value, sl = item % (FD + 1), tt = item / KS, ks = item % KS;
+              if constexpr (ks == 0) {
+                const int tp = g * GT + tt, dy = tp / 3, dx = tp - dy * 3;
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  const int yy = ((mj[j] >> HL) & (H - 1)) + dy - 1, xx = (mj[j] & (H - 1)) + dx - 1;
+                  const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;  // else: conv padding
+                  const int q = ok ? mj[j] + (dy - 1) * H + (dx - 1) : mj[j];
+                  rowa[j] = pl + q * (KC * 2);
+                  hs[j] = (h * 16) ^ (((q >> 1) & (SLOTS - 1)) << 4);
+                  mcur[j] = ok ? 0xFFFFFFFFu : 0u;
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) mvs[sl][j] = mcur[j];
+              static_for<WCB>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
+              });
+              static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
+            };
+            issue(std::integral_constant<int, 0>{});
+            if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
+            static_for<NITEM>([&](auto ic) {
+              constexpr int item = decltype(ic)::value, sl = item % (FD + 1);
+              if constexpr (item + FD < NITEM) issue(std::integral_constant<int, item + FD>{});
+              constexpr int younger = (NITEM - 1 - item < FD ? NITEM - 1 - item : FD) * NR;
+              lds_wait<younger>();
+#pragma unroll
+              for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+              half8 bm[WPB];
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) {
+                lds_touch(fb[sl][j]);
+                bm[j] = fb[sl][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
+              }
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], bm[j], acc[i][j], 0, 0, 0);
+            });
+          }
+          // ---- end of step: next ring step landed (ring waves); next sample's regions landed (patch waves) where the
+          // following step reads them ----
+          if (ring_wave) {
+            if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            const bool before_next_sample = last && chunk == NCHUNK - 1 && g == NG - 1;      // regions 0 .. NCHUNK-2
+            const bool before_last_region = cvi == 0 && chunk == NCHUNK - 2 && g == NG - 1;  // region NCHUNK-1
+            if (before_next_sample || before_last_region) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          asm volatile("s_barrier" ::: "memory");
+          --ahead;
+          if (++slot_rd == NBUF) slot_rd = 0;
+        }
+      }
+      // every wave is past the last step's barrier: nobody reads the activation buffer any more
+      if constexpr (last) {
+        if (has_next) dma_region(t + tstep, NCHUNK - 1);
+        float4v bq[WCB][4], bsq[1][4];
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+        ConvArgs ea{};
+        ea.y = a.y; ea.gap = a.gap; ea.gap_slots = a.gap_slots; ea.gap_l = a.gap_l; ea.acc_scale = cv.acc_scale; ea.relu = 1;
+        ea.res = RES ? (const void *)a.x : nullptr;  // non-NULL = "add resv"
+        float16v acc_sc[1][1];
+        uint4v resl[1][1][2];
+        if constexpr (RES == 2) {
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = keep[i][j][qq];
+        }
+        conv_epilogue<C, CT, WCB, WPB, false, 1>(ea, 0, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+      } else {
+        // + bias (+ residual) (ReLU) -> fp16 -> back into the activation buffer (input of the next conv)
+#pragma unroll
+        for (int i = 0; i < WCB; ++i) {
+          float4v bi[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bi[q] = *(const float4v *)(cv.bias + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+#pragma unroll
+          for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              half4 ra, rb, hq[2];
+              if constexpr (RES != 0) unpair16(RES == 2 ? keep[i][j][qq] : resv[i][j][qq], ra, rb);
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float x = acc[i][j][4 * (2 * qq + k) + e] * cv.acc_scale + bi[2 * qq + k][e];
+                  if constexpr (RES != 0) x += (float)(k ? rb[e] : ra[e]);
+                  hq[k][e] = (_Float16)fmaxf(x, 0.f);
+                }
+              const uint4v w = pair16(hq[0], hq[1]);  // this lane: channels cb .. cb+7 of pixel mj[j]
+              const int cb = (wc * WCB + i) * 32 + 16 * qq + 8 * h;
+              *(uint4v *)(smem + (cb / KC) * REGION + mj[j] * (KC * 2) + ((((cb % KC) / 8) ^ ((mj[j] >> 1) & (SLOTS - 1))) << 4)) = w;
+              if constexpr (SAVE) keep[i][j][qq] = w;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    });
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused identity BasicBlock for the 32-channel stage (layer0.1, arch:52-57 with identity shortcut):
 //     out = relu( bn2(conv2( relu(bn1(conv1(x))) )) + x )
@@ -2280,6 +2559,34 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, CFG_GTE_S2, 2, 2, 5, 3, 1)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, CFG_GTE_S1, 2, 2, 3, 2, 1)
   CONV_CASE(96, 128, 2, true, 32, 32, 2, 2, 2, 2, 2, CFG_GTE_S2, 2, 2, 5, 3, 1)
+  return hipErrorInvalidValue;
+}
+
+// fused chain kernels: (channels, map height) -> instantiation.  128@16: one sample per 16-wave workgroup, weights packed for
+// 128-cout tiles / 64-channel chunks / 3 taps per step (the stand-alone layer's packing).
+bool mlt_chain_supported(int c, int h) { return c == 128 && h == 16; }
+
+#ifndef CFG_CHAIN_FD   // fragment prefetch distance of chain_kernel (items)
+#define CFG_CHAIN_FD 2
+#endif
+hipError_t mlt_launch_chain(int c, int h, const ChainArgs &a, int grid_x, hipStream_t st) {
+  if (c == 128 && h == 16 && (a.nconv == 2 || a.nconv == 3)) {
+    constexpr int lds = 2 * (256 * 64 * 2) + 2 * (CFG_BIG_GT * 4 * 4 * 1024);
+    static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel<128,...> reads the packing of the stand-alone 128->128 layer");
+    // 8 waves x (64 couts x 64 pixels): 256-VGPR budget, one workgroup per CU (its LDS is full)
+    if (a.nconv == 3) {
+      auto kern = chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3>;
+      static DeviceOnce once;
+      if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_x), dim3(512), lds, st, a);
+    } else {
+      auto kern = chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2>;
+      static DeviceOnce once;
+      if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_x), dim3(512), lds, st, a);
+    }
+    return hipGetLastError();
+  }
   return hipErrorInvalidValue;
 }
 
