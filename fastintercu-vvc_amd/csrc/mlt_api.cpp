@@ -350,12 +350,14 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
 
 // Whole layer0.0 (composed first layer + conv2 + shortcut + relu) from the raw planes in one kernel (fast, H >= 32).
 int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
-                   long pred_rs, long pred_cs, void *y) {
+                   long pred_rs, long pred_cs, void *y, int32_t *d_flat) {
   const int h = S / 2;
   const mlt::PackedConv &c2 = m.blocks[0][0].conv2;
   StemBlockArgs a{};
   a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
   a.w = m.stem.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
+  a.flat = d_flat;
+  if (d_flat) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
@@ -404,7 +406,9 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   const int hw = h * h;
   a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
-  const int grid_x = n > wg_cap ? wg_cap : n;  // one sample per workgroup, one workgroup per CU (its LDS is full), persistent
+  const int spw = c == 256 ? 2 : 1;            // samples per workgroup (64 KiB of activations)
+  const int ntiles = (n + spw - 1) / spw;
+  const int grid_x = ntiles > wg_cap ? wg_cap : ntiles;  // one workgroup per CU (its LDS is full), persistent over tiles
   char name[48];
   std::snprintf(name, sizeof name, "chain3_s1_%d_h%d(conv2+conv1+conv2)", c, h);
   const double px = (double)n * hw;
@@ -421,8 +425,10 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
 }
 
 // One chunk of n CUs through the whole network, everything on ctx->stream.
+// d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
+// the raw planes as aligned quads, else by flat_stat_kernel)
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
-                long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits) {
+                long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
   const int S = st.size;
   int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
   if (rc) return rc;
@@ -463,17 +469,28 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
     const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
     const bool fused_b0 = s == 0 && !m.exact && ho >= 32 && !no_fuse0 && quad_ok;
+    if (s == 0 && d_flat && !fused_b0) {
+      FlatStatArgs fa{};
+      fa.org = d_org; fa.pred = d_pred; fa.org_row_stride = org_rs; fa.org_cu_stride = org_cs; fa.pred_row_stride = pred_rs;
+      fa.pred_cu_stride = pred_cs; fa.flat = d_flat; fa.n = n; fa.s_l = ilog2(S);
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
+      HIP_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
+      if ((rc = L.prof_end(e1))) return rc;
+    }
     if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;
-      if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2]))) return rc;
+      if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
     } else {
       if (s == 0) {
         hout = ho;
         if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
       static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-      if (s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], hout) && B0.conv2.taps == 9 && B0.conv2.kc == 64 && B0.conv2.ct == m.planes[s] &&
-          B0.conv2.gt == 3) {  // rest of the stage in one launch: activations stay in LDS, b0 in registers
+      // (small launches keep the per-conv latency variants: a chain runs its convs one after the other on n workgroups)
+      static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+      if (s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], hout) && B0.conv2.taps == 9 && B0.conv2.kc == 64 && B0.conv2.ct == 128 &&
+          B0.conv2.gt == 3 && (long)n * hout * hout > chain_min_px) {  // rest of the stage in one launch: activations stay in LDS, b0 in registers
         if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s]))) return rc;
         cur = outs[s];
         h = hout;
@@ -578,16 +595,9 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc;
-  if (st.flat_guard) {
-    FlatStatArgs fa{};
-    fa.org = pl.org; fa.pred = pl.pred; fa.org_row_stride = pl.org_rs; fa.org_cu_stride = pl.org_cs; fa.pred_row_stride = pl.pred_rs;
-    fa.pred_cu_stride = pl.pred_cs; fa.flat = g.d_flat; fa.n = n; fa.s_l = ilog2(S);
-    if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
-    HIP_TRY(ctx, mlt_launch_flat_stat(fa, pl.aligned8(), ctx->stream));
-    if ((rc = L.prof_end(e1))) return rc;
-  }
   float *lg = d_logits ? d_logits : (st.margin_guard ? g.d_lg : nullptr);
-  if ((rc = run_network(ctx, st, st.model, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg))) return rc;
+  if ((rc = run_network(ctx, st, st.model, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
+                        st.flat_guard ? g.d_flat : nullptr))) return rc;
   GuardSelectArgs sa{};
   sa.flat = st.flat_guard ? g.d_flat : nullptr;
   sa.logits = st.margin_guard ? lg : nullptr;

@@ -62,6 +62,8 @@ struct StemBlockArgs {
   const void *w2;              // layer0.0.conv2 packed weights (18 KiB)
   const float *bias, *bias_sc, *bias2;
   void *y;                     // b0 [n][H][H][32] fp16
+  int32_t *flat;               // NULL, or [n] zero-initialised: += number of exactly-constant 4-pixel quads of each CU
+                               // (flat-content guard; same statistic as flat_stat_kernel)
   float acc_scale;             // composed-weight storage scale (2^-12)
   int n, hout_l, ntiles;       // H = 1 << hout_l (>= 32), picture 2H x 2H; tiles of 16 x 32 output pixels
 };

@@ -1290,17 +1290,24 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
 //     epilogue and the next sample's first chunk.
 // Bit-identical to the three stand-alone launches (same k order, same rounding points: fp16 activations between convs).
 // ---------------------------------------------------------------------------------------------
-template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV>
+//   * C = 256 (8 x 8 maps, two samples per workgroup): the couts are computed in NPASS = 2 passes of 128 (the stand-alone
+//     layer's weight packing); a pass cannot overwrite the buffer while the other still reads it, so pass 0 holds its
+//     activated tile in registers (16 VGPRs) until pass 1 has finished.
+template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
   constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = TAPS / GT;
-  constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NW = WAVES_C * WAVES_P;
+  constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NPASS = C / CT, NW = WAVES_C * WAVES_P;
   constexpr int H = 1 << HL, HW = H * H, M = HW << SPW_L;
-  static_assert(CT == C && M == 32 * WAVES_P * WPB && TAPS % GT == 0 && HW >= 32 && C % KC == 0, "tiling");
+  static_assert(C % CT == 0 && NPASS <= 2 && M == 32 * WAVES_P * WPB && TAPS % GT == 0 && HW >= 32 && C % KC == 0, "tiling");
   constexpr int WCHUNK = GT * KS * CBT * 1024, NPIECE = WCHUNK / 1024, NBUF = RB, PFD = RB - 1;
-  constexpr int NWR = NW / 2, NWP = NW - NWR, PPWR = (NPIECE + NWR - 1) / NWR;
+  // SPLIT_ROLES: first half of the waves issues the ring DMA (and waits for it every step), second half the activation DMA;
+  // otherwise every wave issues its share of both and waits for everything it issued at the end of a step
+  constexpr int NWR = SPLIT_ROLES ? NW / 2 : NW, NWP = SPLIT_ROLES ? NW - NWR : NW, WP0 = SPLIT_ROLES ? NWR : 0;
+  constexpr int PPWR = (NPIECE + NWR - 1) / NWR;
   constexpr int REGION = M * KC * 2, ACT = NCHUNK * REGION, RPIECE = REGION / 1024, PPR = (RPIECE + NWP - 1) / NWP;
   static_assert(ACT + NBUF * WCHUNK <= 160 * 1024, "LDS");
   static_assert(RB == 2 || RB == 3, "ring depth");
+  static_assert(SPLIT_ROLES || RB == 2, "unified issue waits with vmcnt(0)");
   static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
   static_assert(((GT * KS - 1) * CBT + WCB - 1) * 1024 < 65536, "fragment offsets are ds_read immediates");
 
@@ -1311,28 +1318,44 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % WAVES_C, wp = wave / WAVES_C;
   const int p = lane & 31, h = lane >> 5;
-  const bool ring_wave = wave < NWR, patch_wave = !ring_wave;
+  const bool ring_wave = wave < NWR, patch_wave = wave >= WP0;
   const int lane16 = lane * 16;
 
-  // lane -> pixels (lane ranking: every 16-lane ds_read_b128 group owns 16 consecutive pixels, see conv_mfma_kernel)
+  // lane -> pixels: EXACTLY the map of the stand-alone kernels (lane ranking; on 8-wide maps a 16-lane ds_read_b128 group
+  // owns rows a and a + 4 of a sample), so that the fp32 GAP butterfly adds the same pixels in the same order and the
+  // logits are bit-identical whichever kernel variant serves a batch.  mj: logical position (GAP slot), pj: pixel
+  // (sample, y, x) = its LDS slot.
   const int pr = p < 4 ? p : p < 12 ? p + 12 : p < 16 ? p - 8 : p < 20 ? p + 8 : p < 28 ? p - 12 : p;
-  int mj[WPB];  // pixel index inside the tile = its LDS pixel slot; packs (sample, y, x)
+  int mj[WPB], pj[WPB];
 #pragma unroll
-  for (int j = 0; j < WPB; ++j) mj[j] = (wp * WPB + j) * 32 + pr;
+  for (int j = 0; j < WPB; ++j) {
+    mj[j] = (wp * WPB + j) * 32 + pr;
+    if constexpr (HL == 3) {
+      const int q = mj[j] >> 3, k = q & 7;
+      pj[j] = ((q & ~7) | ((k & 1) << 2) | (k >> 1)) * 8 + (mj[j] & 7);
+    } else pj[j] = mj[j];
+  }
+  // 16-byte channel slot swizzle of pixel q: two pixels share a 256-byte bank row; on 8-wide maps bit 5 of q (row a vs
+  // a + 4) is folded in so that the two rows of a lane group use disjoint columns
+  auto swz = [](int q) { return ((q >> 1) & (SLOTS - 1)) ^ (HL == 3 ? ((q >> 5) & 1) << 2 : 0); };
 
   const int ntiles = (a.n + (1 << SPW_L) - 1) >> SPW_L;
   int t = blockIdx.x;
   const int tstep = gridDim.x;
   if (t >= ntiles) return;
 
-  // ---- weight ring: one global step sequence (sample, conv, chunk, tap group) ----
-  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCONV * NCHUNK * NG;
-  int r_cv = 0, r_ci = 0, r_gi = 0, slot_wr = 0, ahead = 0;
+  // ---- weight ring: one global step sequence (sample, conv, cout pass, chunk, tap group) ----
+  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCONV * NPASS * NCHUNK * NG;
+  int r_cv = 0, r_ps = 0, r_ci = 0, r_gi = 0, slot_wr = 0, ahead = 0;
   auto issue_ring = [&]() {
     if (steps_to_issue <= 0) return;
+#ifdef KO_CH_RING
+    if (false) {
+#else
     if (ring_wave) {
+#endif
       const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
-      const char *src = wsrc + (size_t)(r_ci * TAPS + r_gi * GT) * (KS * CBT * 1024);
+      const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
       char *dst = ring + slot_wr * WCHUNK;
 #pragma unroll
       for (int k = 0; k < PPWR; ++k) {
@@ -1343,7 +1366,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     }
     --steps_to_issue;
     ++ahead;
-    if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_cv == NCONV) r_cv = 0; } }
+    if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_ps == NPASS) { r_ps = 0; if (++r_cv == NCONV) r_cv = 0; } } }
     if (++slot_wr == NBUF) slot_wr = 0;
   };
   // ---- activation regions (patch waves): item it = (pixel q, position pos) at byte it * 16 of the region holds channel slot
@@ -1352,10 +1375,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     if (!patch_wave) return;
 #pragma unroll
     for (int k = 0; k < PPR; ++k) {
-      const int piece = (wave - NWR) + k * NWP;
+      const int piece = (wave - WP0) + k * NWP;
       if (piece >= RPIECE) break;  // wave-uniform
       const int it = piece * 64 + lane, q = it / SLOTS, pos = it & (SLOTS - 1);
-      const int sl = pos ^ ((q >> 1) & (SLOTS - 1));
+      const int sl = pos ^ swz(q);
       int n = (tile << SPW_L) + (q >> (2 * HL));
       n = n < a.n ? n : a.n - 1;  // ragged last tile: a valid sample again (its outputs are masked)
       const char *src = (const char *)a.x + (((size_t)n * HW + (q & (HW - 1))) * C + c * KC + sl * 8) * 2;
@@ -1371,179 +1394,217 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   int slot_rd = 0;
-  uint4v keep[WCB][WPB][2];  // residual tile saved by an earlier conv of the chain (packed fp16, pair16 layout)
+  uint4v keep[NPASS][WCB][WPB][2];  // residual tile saved by an earlier conv of the chain (packed fp16, pair16 layout)
 #pragma unroll
-  for (int i = 0; i < WCB; ++i)
+  for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-    for (int j = 0; j < WPB; ++j)
+    for (int i = 0; i < WCB; ++i)
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) keep[i][j][qq] = uint4v{0u, 0u, 0u, 0u};
+      for (int j = 0; j < WPB; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) keep[ps][i][j][qq] = uint4v{0u, 0u, 0u, 0u};
 
   for (; t < ntiles; t += tstep) {
     // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
 #pragma unroll
-    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(mj[j]));
+    for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(pj[j]));
     const bool has_next = t + tstep < ntiles;
     int opix[WPB], gidx[WPB];  // flattened (n, y, x) of this lane's output pixels, GAP partial-sum rows
 #pragma unroll
     for (int j = 0; j < WPB; ++j) {
-      const int nn = (t << SPW_L) + (mj[j] >> (2 * HL));
+      const int nn = (t << SPW_L) + (pj[j] >> (2 * HL));
       const bool ok = nn < a.n;
-      opix[j] = ok ? nn * HW + (mj[j] & (HW - 1)) : -1;
+      opix[j] = ok ? nn * HW + (pj[j] & (HW - 1)) : -1;
       gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
     }
 
     static_for<NCONV>([&](auto kc) {
       constexpr int cvi = decltype(kc)::value;
-      constexpr bool last = cvi == NCONV - 1;
+      constexpr bool lastc = cvi == NCONV - 1;
       const ChainConv &cv = a.cv[cvi];
       // the two chains there are (host: run_chain): NCONV == 3: conv2(+sc from HBM, saved) -> conv1 -> conv2(+saved tile);
       // NCONV == 2: conv1 -> conv2(+x from HBM); every conv is followed by a ReLU
       constexpr int RES = NCONV == 3 ? (cvi == 0 ? 1 : cvi == 2 ? 2 : 0) : (cvi == 1 ? 1 : 0);
       constexpr bool SAVE = NCONV == 3 && cvi == 0;
-      float16v acc[WCB][WPB];
-#pragma unroll
-      for (int i = 0; i < WCB; ++i)
-#pragma unroll
-        for (int j = 0; j < WPB; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      uint4v resv[WCB][WPB][2];
-
-#pragma unroll 1
-      for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-        const uint32_t pl = lds0 + chunk * REGION;
-#pragma unroll 1
-        for (int g = 0; g < NG; ++g) {
-          issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
-          // the last conv has finished reading region chunk-1: the next sample's input may land there
-          if (last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
-          if (RES == 1 && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
-#pragma unroll
-            for (int i = 0; i < WCB; ++i)
-#pragma unroll
-              for (int j = 0; j < WPB; ++j) {
-                const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * C + (wc * WCB + i) * 32 + 8 * h;
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)cv.res + o + 16 * qq);
-              }
-          }
-          {
-            constexpr int NITEM = GT * KS, NR = WCB + WPB;
-            const uint32_t wb = lds0 + ACT + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
-            half8 fa[FD + 1][WCB], fb[FD + 1][WPB];
-            uint32_t rowa[WPB], hs[WPB], mcur[WPB], mvs[FD + 1][WPB];
-            auto issue = [&](auto ic) {
-              constexpr int item = decltype(ic)::value, sl = item % (FD + 1), tt = item / KS, ks = item % KS;
-              if constexpr (ks == 0) {
-                const int tp = g * GT + tt, dy = tp / 3, dx = tp - dy * 3;
-#pragma unroll
-                for (int j = 0; j < WPB; ++j) {
-                  const int yy = ((mj[j] >> HL) & (H - 1)) + dy - 1, xx = (mj[j] & (H - 1)) + dx - 1;
-                  const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;  // else: conv padding
-                  const int q = ok ? mj[j] + (dy - 1) * H + (dx - 1) : mj[j];
-                  rowa[j] = pl + q * (KC * 2);
-                  hs[j] = (h * 16) ^ (((q >> 1) & (SLOTS - 1)) << 4);
-                  mcur[j] = ok ? 0xFFFFFFFFu : 0u;
-                }
-              }
-#pragma unroll
-              for (int j = 0; j < WPB; ++j) mvs[sl][j] = mcur[j];
-              static_for<WCB>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
-              });
-              static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
-            };
-            issue(std::integral_constant<int, 0>{});
-            if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
-            static_for<NITEM>([&](auto ic) {
-              constexpr int item = decltype(ic)::value, sl = item % (FD + 1);
-              if constexpr (item + FD < NITEM) issue(std::integral_constant<int, item + FD>{});
-              constexpr int younger = (NITEM - 1 - item < FD ? NITEM - 1 - item : FD) * NR;
-              lds_wait<younger>();
-#pragma unroll
-              for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
-              half8 bm[WPB];
-#pragma unroll
-              for (int j = 0; j < WPB; ++j) {
-                lds_touch(fb[sl][j]);
-                bm[j] = fb[sl][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
-              }
-#pragma unroll
-              for (int i = 0; i < WCB; ++i)
-#pragma unroll
-                for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], bm[j], acc[i][j], 0, 0, 0);
-            });
-          }
-          // ---- end of step: next ring step landed (ring waves); next sample's regions landed (patch waves) where the
-          // following step reads them ----
-          if (ring_wave) {
-            if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          } else {
-            const bool before_next_sample = last && chunk == NCHUNK - 1 && g == NG - 1;      // regions 0 .. NCHUNK-2
-            const bool before_last_region = cvi == 0 && chunk == NCHUNK - 2 && g == NG - 1;  // region NCHUNK-1
-            if (before_next_sample || before_last_region) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          asm volatile("s_barrier" ::: "memory");
-          --ahead;
-          if (++slot_rd == NBUF) slot_rd = 0;
-        }
-      }
-      // every wave is past the last step's barrier: nobody reads the activation buffer any more
-      if constexpr (last) {
-        if (has_next) dma_region(t + tstep, NCHUNK - 1);
-        float4v bq[WCB][4], bsq[1][4];
+      uint4v hold[WCB][WPB][2];  // NPASS == 2: pass 0's activated tile until pass 1 has finished reading the buffer
+      static_for<NPASS>([&](auto kp) {
+        constexpr int ps = decltype(kp)::value;
+        constexpr bool last = lastc && ps == NPASS - 1;  // the very last K loop over the buffer for this sample
+        float16v acc[WCB][WPB];
 #pragma unroll
         for (int i = 0; i < WCB; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-        ConvArgs ea{};
-        ea.y = a.y; ea.gap = a.gap; ea.gap_slots = a.gap_slots; ea.gap_l = a.gap_l; ea.acc_scale = cv.acc_scale; ea.relu = 1;
-        ea.res = RES ? (const void *)a.x : nullptr;  // non-NULL = "add resv"
-        float16v acc_sc[1][1];
-        uint4v resl[1][1][2];
-        if constexpr (RES == 2) {
+          for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        uint4v resv[WCB][WPB][2];
+
+#pragma unroll 1
+        for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+          const uint32_t pl = lds0 + chunk * REGION;
+#pragma unroll 1
+          for (int g = 0; g < NG; ++g) {
+            issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
+            // the last K loop has finished reading region chunk-1: the next sample's input may land there
+            if (last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
+            if (RES == 1 && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * C + ps * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+                  for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)cv.res + o + 16 * qq);
+                }
+            }
+            {
+              constexpr int NITEM = GT * KS, NR = WCB + WPB;
+              const uint32_t wb = lds0 + ACT + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
+              half8 fa[FD + 1][WCB], fb[FD + 1][WPB];
+              uint32_t rowa[WPB], hs[WPB], mcur[WPB], mvs[FD + 1][WPB];
+              auto issue = [&](auto ic) {
+                constexpr int item = decltype(ic)::value, sl = item % (FD + 1), tt = item / KS, ks = item % KS;
+                if constexpr (ks == 0) {
+                  const int tp = g * GT + tt, dy = tp / 3, dx = tp - dy * 3;
+#pragma unroll
+                  for (int j = 0; j < WPB; ++j) {
+                    const int yy = ((pj[j] >> HL) & (H - 1)) + dy - 1, xx = (pj[j] & (H - 1)) + dx - 1;
+                    const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;  // else: conv padding
+                    const int q = ok ? pj[j] + (dy - 1) * H + (dx - 1) : pj[j];
+                    rowa[j] = pl + q * (KC * 2);
+                    hs[j] = (h * 16) ^ (swz(q) << 4);
+                    mcur[j] = ok ? 0xFFFFFFFFu : 0u;
+                  }
+                }
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) mvs[sl][j] = mcur[j];
+#ifndef KO_CH_READS
+                static_for<WCB>([&](auto ii) {
+                  constexpr int i = decltype(ii)::value;
+                  lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
+                });
+                static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
+#else
+#pragma unroll
+                for (int i = 0; i < WCB; ++i) { half8 &r = fa[sl][i]; const uint32_t ad = wb; asm volatile("" : "=v"(r) : "v"(ad)); }
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) { half8 &r = fb[sl][j]; const uint32_t ad = rowa[j] + (hs[j] ^ (ks * 32)); asm volatile("" : "=v"(r) : "v"(ad)); }
+#endif
+              };
+              issue(std::integral_constant<int, 0>{});
+              if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
+              static_for<NITEM>([&](auto ic) {
+                constexpr int item = decltype(ic)::value, sl = item % (FD + 1);
+                if constexpr (item + FD < NITEM) issue(std::integral_constant<int, item + FD>{});
+                constexpr int younger = (NITEM - 1 - item < FD ? NITEM - 1 - item : FD) * NR;
+                lds_wait<younger>();
+#pragma unroll
+                for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+                half8 bm[WPB];
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  lds_touch(fb[sl][j]);
+                  bm[j] = fb[sl][j];
+#ifndef KO_CH_MASK
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
+#endif
+                }
+#pragma unroll
+                for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                  for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], bm[j], acc[i][j], 0, 0, 0);
+              });
+            }
+            // ---- end of step: next ring step landed (ring waves); next sample's regions landed (patch waves) where the
+            // following step reads them ----
+            if constexpr (SPLIT_ROLES) {
+              if (ring_wave) {
+                if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              } else {
+                const bool before_next_sample = last && chunk == NCHUNK - 1 && g == NG - 1;                 // regions 0 .. NCHUNK-2
+                const bool before_last_region = cvi == 0 && ps == 0 && chunk == NCHUNK - 2 && g == NG - 1;  // region NCHUNK-1
+                if (before_next_sample || before_last_region) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              }
+            } else {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#ifndef KO_CH_BARRIER
+            asm volatile("s_barrier" ::: "memory");
+#endif
+            --ahead;
+            if (++slot_rd == NBUF) slot_rd = 0;
+          }
+        }
+        // every wave is past the last step's barrier
+        if constexpr (lastc) {
+          if constexpr (last) {
+            if (has_next) dma_region(t + tstep, NCHUNK - 1);  // nobody reads the activation buffer any more
+          }
+          float4v bq[WCB][4], bsq[1][4];
 #pragma unroll
           for (int i = 0; i < WCB; ++i)
 #pragma unroll
+            for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+          ConvArgs ea{};
+          ea.y = a.y; ea.gap = a.gap; ea.gap_slots = a.gap_slots; ea.gap_l = a.gap_l; ea.acc_scale = cv.acc_scale; ea.relu = 1;
+          ea.res = RES ? (const void *)a.x : nullptr;  // non-NULL = "add resv"
+          float16v acc_sc[1][1];
+          uint4v resl[1][1][2];
+          if constexpr (RES == 2) {
+#pragma unroll
+            for (int i = 0; i < WCB; ++i)
+#pragma unroll
+              for (int j = 0; j < WPB; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = keep[ps][i][j][qq];
+          }
+          conv_epilogue<C, CT, WCB, WPB, false, 1>(ea, ps, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+        } else {
+          // + bias (+ residual) (ReLU) -> fp16 -> back into the activation buffer (input of the next conv)
+          auto put = [&](int pass, int i, int j, int qq, uint4v w) {  // this lane: channels cb .. cb+7 of pixel pj[j]
+            const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
+            *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = w;
+          };
+#pragma unroll
+          for (int i = 0; i < WCB; ++i) {
+            float4v bi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bi[q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+#pragma unroll
             for (int j = 0; j < WPB; ++j)
 #pragma unroll
-              for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = keep[i][j][qq];
-        }
-        conv_epilogue<C, CT, WCB, WPB, false, 1>(ea, 0, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
-      } else {
-        // + bias (+ residual) (ReLU) -> fp16 -> back into the activation buffer (input of the next conv)
+              for (int qq = 0; qq < 2; ++qq) {
+                half4 ra, rb, hq[2];
+                if constexpr (RES != 0) unpair16(RES == 2 ? keep[ps][i][j][qq] : resv[i][j][qq], ra, rb);
 #pragma unroll
-        for (int i = 0; i < WCB; ++i) {
-          float4v bi[4];
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) bi[q] = *(const float4v *)(cv.bias + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+                  for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * (2 * qq + k) + e] * cv.acc_scale + bi[2 * qq + k][e];
+                    if constexpr (RES != 0) x += (float)(k ? rb[e] : ra[e]);
+                    hq[k][e] = (_Float16)fmaxf(x, 0.f);
+                  }
+                const uint4v w = pair16(hq[0], hq[1]);
+                if constexpr (SAVE) keep[ps][i][j][qq] = w;
+                if constexpr (ps == NPASS - 1) put(ps, i, j, qq, w);
+                else hold[i][j][qq] = w;
+              }
+          }
+          if constexpr (ps == NPASS - 1) {
+            if constexpr (NPASS == 2) {
 #pragma unroll
-          for (int j = 0; j < WPB; ++j)
+              for (int i = 0; i < WCB; ++i)
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              half4 ra, rb, hq[2];
-              if constexpr (RES != 0) unpair16(RES == 2 ? keep[i][j][qq] : resv[i][j][qq], ra, rb);
+                for (int j = 0; j < WPB; ++j)
 #pragma unroll
-              for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float x = acc[i][j][4 * (2 * qq + k) + e] * cv.acc_scale + bi[2 * qq + k][e];
-                  if constexpr (RES != 0) x += (float)(k ? rb[e] : ra[e]);
-                  hq[k][e] = (_Float16)fmaxf(x, 0.f);
-                }
-              const uint4v w = pair16(hq[0], hq[1]);  // this lane: channels cb .. cb+7 of pixel mj[j]
-              const int cb = (wc * WCB + i) * 32 + 16 * qq + 8 * h;
-              *(uint4v *)(smem + (cb / KC) * REGION + mj[j] * (KC * 2) + ((((cb % KC) / 8) ^ ((mj[j] >> 1) & (SLOTS - 1))) << 4)) = w;
-              if constexpr (SAVE) keep[i][j][qq] = w;
+                  for (int qq = 0; qq < 2; ++qq) put(0, i, j, qq, hold[i][j][qq]);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      }
+      });
     });
   }
 }
@@ -1961,30 +2022,37 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
       const int iy = iy0 + ry, ix = ix0 + 4 * qx;
       const bool in_items = it < RH * QW;
       const bool live = in_items && iy >= 0 && iy < S && ix >= 0 && ix < S;
-      rdst[u] = in_items ? (ry * RP + 2 * qx) | (live ? 0 : 1 << 30) : -1;
+      // bit 29: the quad lies in the part of the raw patch only THIS tile owns (rows / columns of its 32 x 64 input
+      // pixels without the halo) -> counted once for the flat-content guard
+      const bool own = in_items && ry >= 4 && ry < 4 + 2 * TH && qx >= 1 && qx <= 2 * TW / 4;
+      rdst[u] = in_items ? (ry * RP + 2 * qx) | (live ? 0 : 1 << 30) | (own ? 1 << 29 : 0) : -1;
       const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + ((tid * 4) & (S - 1));
       const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + ((tid * 4) & (S - 1));
       vo[u] = *(const uint2v *)(a.org + oo);
       vp[u] = *(const uint2v *)(a.pred + po);
     }
   };
-  auto commit_raw = [&]() {
+  auto commit_raw = [&](int n) {
+    int nflat = 0;  // wave-uniform: own quads whose four (org, |org - pred|) pairs are identical (flat_stat_kernel's statistic)
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      if (rdst[u] < 0) continue;
+      const bool item = rdst[u] >= 0;
       const bool zf = rdst[u] & (1 << 30);
-      const int d = rdst[u] & ~(1 << 30);
+      const int d = rdst[u] & ~(3 << 29);
       uint32_t w[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int16_t o = (int16_t)(vo[u][j >> 1] >> (16 * (j & 1))), q = (int16_t)(vp[u][j >> 1] >> (16 * (j & 1)));
         w[j] = zf ? 0u : prep_pair(o, q);
       }
+      if (a.flat) nflat += __builtin_popcountll(__ballot(item && (rdst[u] & (1 << 29)) && w[1] == w[0] && w[2] == w[0] && w[3] == w[0]));
+      if (!item) continue;
       uint2v ev, od;  // parity-split columns: pixels 0, 2 -> even half, 1, 3 -> odd half (8-byte stores)
       ev[0] = w[0]; ev[1] = w[2]; od[0] = w[1]; od[1] = w[3];
       *(uint2v *)(raw + d) = ev;
       *(uint2v *)(raw + d + HW) = od;
     }
+    if (a.flat && nflat && lane == 0) atomicAdd(a.flat + n, nflat);  // integer adds: order-independent, deterministic
   };
   auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
   auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
@@ -1996,7 +2064,7 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
     int tx, ty, n;
     tile_decode(t, tx, ty, n);
     PH_MARK(7);
-    commit_raw();
+    commit_raw(n);
     PH_MARK(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PH_MARK(1);
@@ -2564,28 +2632,30 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
 
 // fused chain kernels: (channels, map height) -> instantiation.  128@16: one sample per 16-wave workgroup, weights packed for
 // 128-cout tiles / 64-channel chunks / 3 taps per step (the stand-alone layer's packing).
-bool mlt_chain_supported(int c, int h) { return c == 128 && h == 16; }
+bool mlt_chain_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }
 
-#ifndef CFG_CHAIN_FD   // fragment prefetch distance of chain_kernel (items)
+#ifndef CFG_CHAIN_FD     // fragment prefetch distance of chain_kernel (items)
 #define CFG_CHAIN_FD 2
 #endif
+#ifndef CFG_CHAIN_SPLIT  // 1: ring DMA on the first half of the waves, activation DMA on the second; 0: every wave issues both
+#define CFG_CHAIN_SPLIT 1
+#endif
+template <class K> static hipError_t launch_chain_t(K kern, DeviceOnce &once, const ChainArgs &a, int grid_x, int threads, int lds, hipStream_t st) {
+  if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid_x), dim3(threads), lds, st, a);
+  return hipGetLastError();
+}
 hipError_t mlt_launch_chain(int c, int h, const ChainArgs &a, int grid_x, hipStream_t st) {
-  if (c == 128 && h == 16 && (a.nconv == 2 || a.nconv == 3)) {
-    constexpr int lds = 2 * (256 * 64 * 2) + 2 * (CFG_BIG_GT * 4 * 4 * 1024);
-    static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel<128,...> reads the packing of the stand-alone 128->128 layer");
-    // 8 waves x (64 couts x 64 pixels): 256-VGPR budget, one workgroup per CU (its LDS is full)
-    if (a.nconv == 3) {
-      auto kern = chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3>;
-      static DeviceOnce once;
-      if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid_x), dim3(512), lds, st, a);
-    } else {
-      auto kern = chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2>;
-      static DeviceOnce once;
-      if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid_x), dim3(512), lds, st, a);
-    }
-    return hipGetLastError();
+  static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel reads the packing of the stand-alone 128->128 / 256->256 layers");
+  constexpr int lds = 64 * 1024 + 2 * (CFG_BIG_GT * 4 * 4 * 1024);  // 64 KiB activation + two 48 KiB weight steps = all of the LDS
+  static DeviceOnce once[4];
+  if (c == 128 && h == 16) {  // 8 waves x (64 couts x 64 pixels), one sample per workgroup
+    if (a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[0], a, grid_x, 512, lds, st);
+    if (a.nconv == 2) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[1], a, grid_x, 512, lds, st);
+  }
+  if (c == 256 && h == 8) {   // 8 waves x (64 couts x 32 pixels) x 2 cout passes, two samples per workgroup
+    if (a.nconv == 3) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[2], a, grid_x, 512, lds, st);
+    if (a.nconv == 2) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[3], a, grid_x, 512, lds, st);
   }
   return hipErrorInvalidValue;
 }

@@ -11,10 +11,12 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "big_2wg_gt1": ["CFG_BIG_WP=4", "CFG_BIG_GT=1"],
-    "s2_regstage_gt2": ["CFG_S2A_DMA=0", "CFG_S2B_DMA=0", "CFG_S2B_GT=2"],
-    "dma64_burst": ["CFG_DMA_SPREAD=0"],
-    "base_b": [],
+    "ko_ring": ["KO_CH_RING"],
+    "ko_barrier": ["KO_CH_BARRIER"],
+    "ko_mask": ["KO_CH_MASK"],
+    "ko_reads": ["KO_CH_READS"],
+    "ko_ring_barrier": ["KO_CH_RING", "KO_CH_BARRIER"],
+    "ko_all": ["KO_CH_RING", "KO_CH_BARRIER", "KO_CH_MASK", "KO_CH_READS"],
 }
 
 
@@ -29,7 +31,7 @@ def main():
     else:
         for name in VARIANTS:
             env = dict(os.environ, MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")],
                                  env=env, capture_output=True, text=True).stdout
             line = [l for l in out.splitlines() if l.startswith("{")]
             if not line:
@@ -38,6 +40,8 @@ def main():
             d = json.loads(line[-1])
             print(f"{name:16s} {d['value']:10.0f} CU/s  err {d['parity']['max_abs_dlogit']:.1e}  " +
                   " ".join(f"{k['avg_ms']:.3f}" for k in d["derived"]["kernels"]))
+            if os.environ.get("SWEEP_NAMES") and name == list(VARIANTS)[0]:
+                print(" " * 44 + " ".join(k["name"][:5] for k in d["derived"]["kernels"]))
 
 
 if __name__ == "__main__":
