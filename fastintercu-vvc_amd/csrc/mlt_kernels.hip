@@ -1337,7 +1337,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   }
   // 16-byte channel slot swizzle of pixel q: two pixels share a 256-byte bank row; on 8-wide maps bit 5 of q (row a vs
   // a + 4) is folded in so that the two rows of a lane group use disjoint columns
-  auto swz = [](int q) { return ((q >> 1) & (SLOTS - 1)) ^ (HL == 3 ? ((q >> 5) & 1) << 2 : 0); };
+  // (16-wide maps: bit 4 of q -- the row parity -- is folded in as well, so that the epilogue's ds_write_b128, whose 8-lane groups
+  // cover columns 0-3 of two consecutive rows, is conflict-free too)
+#ifndef CFG_CHAIN_SWZ16
+#define CFG_CHAIN_SWZ16 1
+#endif
+  auto swz = [](int q) { return ((q >> 1) & (SLOTS - 1)) ^ (HL == 3 ? ((q >> 5) & 1) << 2 : CFG_CHAIN_SWZ16 ? ((q >> 4) & 1) << 1 : 0); };
 
   const int ntiles = (a.n + (1 << SPW_L) - 1) >> SPW_L;
   int t = blockIdx.x;

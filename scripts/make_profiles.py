@@ -4,6 +4,7 @@ profiles/<tag>_* files: bench line, rocprofv3 kernel stats, HBM traffic per kern
 MFMA / LDS counter summary.  usage: make_profiles.py gpurun_out/r01g r01g"""
 import collections
 import csv
+import json
 import glob
 import os
 import shutil
@@ -17,9 +18,11 @@ shutil.copy(os.path.join(run, "stats", "out_kernel_stats.csv"), os.path.join(pro
 shutil.copy(os.path.join(run, "bench_line.json"), os.path.join(prof, f"{tag}_bench_line.json"))
 if os.path.exists(os.path.join(run, "bench_extras.json")):
     shutil.copy(os.path.join(run, "bench_extras.json"), os.path.join(prof, f"{tag}_bench_latency_hoststaged.json"))
+sig = json.load(open(os.path.join(run, "bench_line.json")))["derived"]["source_sig"]  # sources the evidence run was built from
 subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_traffic_json.py"),
                        os.path.join(run, "fetch", "out_counter_collection.csv"), os.path.join(run, "write", "out_counter_collection.csv"),
-                       "4096", os.path.join(prof, "pmc_traffic.json")], stdout=subprocess.DEVNULL)
+                       "4096", os.path.join(prof, "pmc_traffic.json"), tag, sig], stdout=subprocess.DEVNULL)
+shutil.copy(os.path.join(prof, "pmc_traffic.json"), os.path.join(prof, f"{tag}_pmc_traffic.json"))
 rows = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(run, "pmc", "*/"))):
     f = os.path.join(d, "out_counter_collection.csv")
@@ -28,7 +31,7 @@ for d in sorted(glob.glob(os.path.join(run, "pmc", "*/"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_" in k or "block" in k or "heads" in k:
+        if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, x in v.items():

@@ -21,6 +21,9 @@ def per_kernel(path, counter):
         if m:
             cin, cout, st = map(int, m.groups())
             name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")
+        elif (mc := re.search(r"chain_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, (\d+)", k)):
+            c, hl, nconv = map(int, mc.groups())
+            name = f"chain{nconv}_s1_{c}_h{1 << hl}(conv2+conv1+conv2)"
         elif "stem_block_kernel" in k:
             name = "stem+block_s2_2to32_h64(layer0.0)"
         elif "block32_kernel" in k:
@@ -38,8 +41,10 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    tag, sig = (sys.argv[5], sys.argv[6]) if len(sys.argv) > 6 else ("?", "?")
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    res = {}
+    # _meta.source_sig: bench.py only quotes these figures while the kernel / runtime sources still hash to it
+    res = {"_meta": {"tag": tag, "source_sig": sig, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 scripts/prof_run.py 4096 2"}}
     for name in f:
         res[f"{name}@{batch}"] = {"batch": batch, "fetch_kib_raw": f[name], "write_kib": w.get(name, 0.0),
                                   "hbm_bytes_per_launch": (2.0 * f[name] + w.get(name, 0.0)) * 1024.0,

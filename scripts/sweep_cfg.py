@@ -11,12 +11,9 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "ko_ring": ["KO_CH_RING"],
-    "ko_barrier": ["KO_CH_BARRIER"],
+    "swz_old": ["CFG_CHAIN_SWZ16=0"],
     "ko_mask": ["KO_CH_MASK"],
-    "ko_reads": ["KO_CH_READS"],
-    "ko_ring_barrier": ["KO_CH_RING", "KO_CH_BARRIER"],
-    "ko_all": ["KO_CH_RING", "KO_CH_BARRIER", "KO_CH_MASK", "KO_CH_READS"],
+    "base_b": [],
 }
 
 
