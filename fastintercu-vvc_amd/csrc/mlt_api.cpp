@@ -152,6 +152,7 @@ int upload_model(mlt_ctx *ctx, mlt::Model &m) {
     for (int b = 0; b < 2; ++b) {
       if ((rc = up(m.blocks[s][b].conv1))) return rc;
       if ((rc = up(m.blocks[s][b].conv2))) return rc;
+      if ((rc = up(m.blocks[s][b].conv1_s2c))) return rc;
     }
   for (int h = 0; h < m.n_heads; ++h) {
     mlt::Head &H = m.heads[h];
@@ -173,7 +174,7 @@ void free_model(mlt::Model &m) {
   };
   fr(m.stem);
   for (int s = 0; s < 5; ++s)
-    for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); }
+    for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); fr(m.blocks[s][b].conv1_s2c); }
   for (int h = 0; h < 4; ++h) { if (m.heads[h].d_w) (void)hipFree(m.heads[h].d_w); if (m.heads[h].d_b) (void)hipFree(m.heads[h].d_b); m.heads[h].d_w = m.heads[h].d_b = nullptr; }
   m.on_device = false;
 }
@@ -394,15 +395,22 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
 
 // BasicBlock tail of a stage as ONE launch (chain_kernel): b0 = relu(bn2(conv2 t) + sc); t1 = relu(bn1(conv1 b0));
 // out = relu(bn2(conv2 t1) + b0) (+ GAP).  Fast arithmetic, stages whose whole sample fits the LDS (128 channels @ 16 x 16).
-int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap) {
+// s2_in != NULL: the stage's stride-2 conv + shortcut run inside the same launch from the stage input s2_in ([n][2h][2h][c/2]);
+// t / sc are then unused.
+int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap,
+               const void *s2_in = nullptr) {
   const int c = B0.conv2.cout;
   ChainArgs a{};
-  a.x = t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n;
+  a.x = s2_in ? s2_in : t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n; a.zero = ctx->zero_page;
   const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
   for (int k = 0; k < 3; ++k) {
     a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
   }
-  a.cv[0].res_mode = 1; a.cv[0].res = sc; a.cv[0].save = 1; a.cv[2].res_mode = 2;
+  a.cv[0].res_mode = s2_in ? 2 : 1; a.cv[0].res = sc; a.cv[0].save = 1; a.cv[2].res_mode = 2;
+  if (s2_in) {
+    const mlt::PackedConv &p2 = B0.conv1_s2c;
+    a.s2_w = p2.d_w; a.s2_bias = p2.d_bias; a.s2_bias_sc = p2.d_bias_sc; a.s2_scale = p2.acc_scale;
+  }
   const int hw = h * h;
   a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
@@ -410,21 +418,21 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   const int ntiles = (n + spw - 1) / spw;
   const int grid_x = ntiles > wg_cap ? wg_cap : ntiles;  // one workgroup per CU (its LDS is full), persistent over tiles
   char name[48];
-  std::snprintf(name, sizeof name, "chain3_s1_%d_h%d(conv2+conv1+conv2)", c, h);
+  std::snprintf(name, sizeof name, s2_in ? "stage_%d_h%d(s2+sc,conv2,conv1,conv2)" : "chain3_s1_%d_h%d(conv2+conv1+conv2)", c, h);
   const double px = (double)n * hw;
-  const double flops = 3.0 * 2.0 * px * c * c * 9;
-  const double bytes = px * c * 2 * (2 + (y ? 1 : 0)) + 3.0 * (double)B0.conv2.w.size() * 2;
+  const double flops = 3.0 * 2.0 * px * c * c * 9 + (s2_in ? 2.0 * px * c * (c / 2) * 10 : 0.0);
+  const double bytes = (s2_in ? px * 4 * (c / 2) * 2 : px * c * 2 * 2) + (y ? px * c * 2 : 0.0) + 3.0 * (double)B0.conv2.w.size() * 2 +
+                       (s2_in ? (double)B0.conv1_s2c.w.size() * 2 : 0.0);
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_chain(c, h, a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, a, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
   return MLT_OK;
 }
 
-// One chunk of n CUs through the whole network, everything on ctx->stream.
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
 // the raw planes as aligned quads, else by flat_stat_kernel)
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
@@ -482,16 +490,20 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       hout = ho;
       if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
     } else {
+      static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+      static const bool no_chain_s2 = std::getenv("MLT_NO_CHAIN_S2") != nullptr;
+      // (small launches keep the per-conv latency variants: a chain runs its convs one after the other on n workgroups)
+      static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+      const bool chain = s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], ho) && B0.conv2.taps == 9 && B0.conv2.kc == 64 &&
+                         B0.conv2.ct == 128 && B0.conv2.gt == 3 && (long)n * ho * ho > chain_min_px;
+      const bool chain_s2 = chain && !no_chain_s2 && B0.conv1_s2c.d_w != nullptr;  // the stride-2 conv + shortcut join the launch
       if (s == 0) {
         hout = ho;
         if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
-      } else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
-      static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-      // (small launches keep the per-conv latency variants: a chain runs its convs one after the other on n workgroups)
-      static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
-      if (s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], hout) && B0.conv2.taps == 9 && B0.conv2.kc == 64 && B0.conv2.ct == 128 &&
-          B0.conv2.gt == 3 && (long)n * hout * hout > chain_min_px) {  // rest of the stage in one launch: activations stay in LDS, b0 in registers
-        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s]))) return rc;
+      } else if (chain_s2) hout = ho;
+      else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
+        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr))) return rc;
         cur = outs[s];
         h = hout;
         const int hd = s - 1;

@@ -81,7 +81,13 @@ struct ChainConv {
   const void *res;
 };
 struct ChainArgs {
-  const void *x;       // [n][H][H][C] fp16: input of the first conv
+  const void *x;       // [n][H][H][C] fp16: input of the first conv; S2 variant: the STAGE input [n][2H][2H][C/2]
+  // S2 variant (whole stage in one launch): the stage's first conv -- 3x3 stride 2 + its 1x1 stride-2 projection shortcut
+  // (arch:44-55) -- runs in front of the chain; its weights are packed for 16-channel chunks (mlt_model.cpp: conv1_s2c)
+  const void *s2_w;
+  const float *s2_bias, *s2_bias_sc;
+  float s2_scale;
+  const void *zero;    // >= 64 KiB of zeros (padding source of the patch DMA)
   ChainConv cv[3];
   int nconv;           // 2 or 3
   void *y;             // [n][H][H][C] fp16 output of the last conv, or NULL (only the GAP sums are needed)
@@ -89,7 +95,7 @@ struct ChainArgs {
   int gap_slots, gap_l;
   int n;
 };
-hipError_t mlt_launch_chain(int c, int h, const ChainArgs &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int grid_x, hipStream_t st);
 bool mlt_chain_supported(int c, int h);
 
 struct HeadArgs {

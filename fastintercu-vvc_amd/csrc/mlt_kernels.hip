@@ -321,7 +321,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
 //          (CBT divides CBP): blockIdx.y counts the narrower tiles and the weight steps gather their 1 KiB pieces with
 //          the packed stride.  Used by the small-batch ("latency") variants, which spread the couts of a layer over
 //          4x more workgroups than the throughput tiling without a second packed copy of the weights.
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0>
+//   KMAJ   the items of a weight step run k-step-major (all taps of the first 16 channels of the chunk, then of the next 16) instead
+//          of tap-major.  Same products, another fp32 accumulation order: the order of chain_kernel's stride-2 phase, which stages
+//          16 channels at a time -- so the small-launch variants of the stride-2 convs and the whole-stage kernel agree bit for bit.
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0, bool KMAJ = false>
 // MINW = minimum waves per SIMD (second __launch_bounds__ argument, caps the VGPR allocation); 1 = unconstrained
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(CIN % KC == 0 && (KC == 32 || KC == 64), "cin chunking");
@@ -788,8 +791,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
           half8 fa[FDR + 1][WCB], fb[FDR + 1][WPB];
           uint32_t pbt[WPB];
           auto issue = [&](auto ic) {
-            constexpr int item = decltype(ic)::value, sl = item % (FDR + 1), tt = item / KS, ks = item % KS;
-            if constexpr (ks == 0) {
+            constexpr int item = decltype(ic)::value, sl = item % (FDR + 1), tt = KMAJ ? item % GT : item / KS, ks = KMAJ ? item / GT : item % KS;
+            if constexpr (KMAJ || ks == 0) {
               const int toff = tap_off(tt);
 #pragma unroll
               for (int j = 0; j < WPB; ++j) pbt[j] = lds0 + base[j] + toff;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
             for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
 #pragma unroll
             for (int j = 0; j < WPB; ++j) lds_touch(fb[sl][j]);
-            const bool is_sc = SC && (g * GT + item / KS) == TAPS;
+            const bool is_sc = SC && (g * GT + (KMAJ ? item % GT : item / KS)) == TAPS;
             if (is_sc) {
               if constexpr (SC) {
 #pragma unroll
@@ -827,6 +830,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
             }
           });
         } else {
+        static_assert(!KMAJ, "k-step-major items: asm-pipelined path only");
         half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
         auto load_frags = [&](int item, int sl) {
           const int tt = item / KS, ks = item - tt * KS;
@@ -1293,7 +1297,14 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
 //   * C = 256 (8 x 8 maps, two samples per workgroup): the couts are computed in NPASS = 2 passes of 128 (the stand-alone
 //     layer's weight packing); a pass cannot overwrite the buffer while the other still reads it, so pass 0 holds its
 //     activated tile in registers (16 VGPRs) until pass 1 has finished.
-template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES>
+//   * S2 (whole stage in one launch): the stage's first conv -- 3x3 stride 2 (+ bn1 + ReLU) and its 1x1 stride-2 projection
+//     shortcut (+ BN), arch:44-55 -- runs in front of the chain ON THE SAME TILE: its input (C/2 channels at 2H x 2H) is staged
+//     16 channels at a time as a zero-padded, column-parity-split patch ((2H+1)^2 pixels x 32 B, slot-swizzled by bit 3 of the
+//     pixel index) into the then idle activation buffer, double-buffered; 10 weight "taps" (9 + shortcut) of a chunk are one
+//     40 KiB ring step.  t goes straight into the activation buffer, sc into the residual registers: neither touches HBM.
+//     LDS during this phase: patches [0, 2 x PBYTES), ring steps at ACT + 8 KiB and ACT + WCHUNK + 8 KiB -- chosen so that
+//     the first chain step can be prefetched during the last stride-2 step and vice versa (see the hazards at issue_ring).
+template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
   constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = TAPS / GT;
   constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NPASS = C / CT, NW = WAVES_C * WAVES_P;
@@ -1310,6 +1321,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   static_assert(SPLIT_ROLES || RB == 2, "unified issue waits with vmcnt(0)");
   static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
   static_assert(((GT * KS - 1) * CBT + WCB - 1) * 1024 < 65536, "fragment offsets are ds_read immediates");
+  // stride-2 front conv (S2)
+  constexpr int CIN = C / 2, HIN = 2 * H, KCS = 16, NCS = CIN / KCS, TAPS_S = 10, NS = S2 ? NPASS * NCS : 0;
+  constexpr int NCH = NCONV * NPASS * NCHUNK * NG;                       // chain steps per tile
+  constexpr int WSTEP_S = TAPS_S * CBT * 1024, NPIECE_S = WSTEP_S / 1024, PPWR_S = (NPIECE_S + NWR - 1) / NWR;
+  constexpr int PRS = 2 * H + 1, PCW = 2 * H + 1, PPS = PRS * PCW, PPIX = PPS << SPW_L;  // patch rows, columns (H+1 odd + H even), pixels
+  constexpr int PBYTES = (PPIX * KCS * 2 + 1023) / 1024 * 1024, PPIECE = PBYTES / 1024, PPP = (PPIECE + NWP - 1) / NWP;
+  constexpr int SOFF0 = ACT + 8 * 1024, SOFF1 = ACT + WCHUNK + 8 * 1024;  // LDS offsets of the two stride-2 weight steps
+  static_assert(!S2 || (SPLIT_ROLES && RB == 2 && NS % 2 == 0 && NCH % 2 == 0 && (NCS - 1) % 2 == 1), "S2: step parities");
+  static_assert(!S2 || (2 * PBYTES <= SOFF0 && SOFF0 + WSTEP_S <= ACT + WCHUNK && SOFF1 + WSTEP_S <= 160 * 1024), "S2: LDS layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *ring = smem + ACT;
@@ -1349,30 +1369,71 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   const int tstep = gridDim.x;
   if (t >= ntiles) return;
 
-  // ---- weight ring: one global step sequence (sample, conv, cout pass, chunk, tap group) ----
-  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * NCONV * NPASS * NCHUNK * NG;
-  int r_cv = 0, r_ps = 0, r_ci = 0, r_gi = 0, slot_wr = 0, ahead = 0;
+  // ---- weight ring: one global step sequence (sample, [stride-2: cout pass, chunk], conv, cout pass, chunk, tap group) ----
+  // S2 hazards (step i+1 is DMA'd while step i computes; steps of both kinds alternate slots from 0 in every tile):
+  //   last chain step (reads chain slot 1 = [ACT+WCHUNK, ..)) -> next tile's first stride-2 step lands in SOFF0 (inside chain slot 0: free);
+  //   last stride-2 step (odd index: reads SOFF1 and patch buffer 0) -> first chain step lands in chain slot 0 = [ACT, ACT+WCHUNK):
+  //   overlaps only patch buffer 1's tail and SOFF0, both last read one step earlier.
+  int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * (NS + NCH);
+  int r_pos = 0, r_cv = 0, r_ps = 0, r_ci = 0, r_gi = 0, ahead = 0;  // r_pos: position in the tile's NS + NCH steps
   auto issue_ring = [&]() {
     if (steps_to_issue <= 0) return;
+    const bool s_step = S2 && r_pos < NS;
 #ifdef KO_CH_RING
     if (false) {
 #else
     if (ring_wave) {
 #endif
-      const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
-      const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
-      char *dst = ring + slot_wr * WCHUNK;
+      if (s_step) {
+        const char *src = (const char *)a.s2_w + (size_t)r_pos * WSTEP_S;
+        char *dst = smem + ((r_pos & 1) ? SOFF1 : SOFF0);
 #pragma unroll
-      for (int k = 0; k < PPWR; ++k) {
-        int pi = wave + k * NWR;
-        pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
-        glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+        for (int k = 0; k < PPWR_S; ++k) {
+          int pi = wave + k * NWR;
+          pi = pi < NPIECE_S ? pi : NPIECE_S - 1;
+          glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+        }
+      } else {
+        const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
+        const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
+        char *dst = ring + ((r_pos - NS) & 1) * WCHUNK;
+#pragma unroll
+        for (int k = 0; k < PPWR; ++k) {
+          int pi = wave + k * NWR;
+          pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
+          glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+        }
       }
     }
     --steps_to_issue;
     ++ahead;
-    if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_ps == NPASS) { r_ps = 0; if (++r_cv == NCONV) r_cv = 0; } } }
-    if (++slot_wr == NBUF) slot_wr = 0;
+    if (!s_step) {
+      if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_ps == NPASS) { r_ps = 0; if (++r_cv == NCONV) r_cv = 0; } } }
+    }
+    if (++r_pos == NS + NCH) r_pos = 0;
+  };
+  // ---- S2: input patch of stride-2 step i (16 channels, chunk i % NCS) -> patch buffer (i + 1) & 1 (patch waves).  Patch pixel
+  // qS = (sample * PRS + r) * PCW + k holds input pixel (r - 1, k <= H ? 2k - 1 : 2(k - H - 1)); its two 16-byte channel slots are
+  // swapped when bit 3 of qS is set (16 consecutive patch pixels span two 256-byte bank rows).  Outside the picture: zero page.
+  auto patch_dma = [&](int tile, int i) {
+    if (!patch_wave) return;
+    const int chunk = i % NCS;
+    char *dst = smem + (((i + 1) & 1) ? PBYTES : 0);
+#pragma unroll
+    for (int k = 0; k < PPP; ++k) {
+      const int piece = (wave - WP0) + k * NWP;
+      if (piece >= PPIECE) break;  // wave-uniform
+      const int it = piece * 64 + lane, qS = it >> 1, pos = it & 1;
+      const int sl = pos ^ ((qS >> 3) & 1);
+      const int sm = qS / PPS, rem = qS - sm * PPS, r = rem / PCW, kk = rem - r * PCW;
+      const int ri = r - 1, ci = kk <= H ? 2 * kk - 1 : 2 * (kk - H - 1);
+      int n = (tile << SPW_L) + sm;
+      n = n < a.n ? n : a.n - 1;
+      const bool live = qS < PPIX && ri >= 0 && ri < HIN && ci >= 0 && ci < HIN;
+      const char *src = live ? (const char *)a.x + ((((size_t)n * HIN + ri) * HIN + ci) * CIN + chunk * KCS + sl * 8) * 2
+                             : (const char *)a.zero + ((((int)blockIdx.x * 64 * NW + tid) * 16) & 0xFFF0);
+      glds16(src, dst + piece * 1024);
+    }
   };
   // ---- activation regions (patch waves): item it = (pixel q, position pos) at byte it * 16 of the region holds channel slot
   // pos ^ ((q >> 1) & 7) of that pixel ----
@@ -1392,14 +1453,20 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   };
 
   // ---- prologue ----
+  if constexpr (S2) {
+    patch_dma(t, 0);
+    patch_dma(t, 1);
+  } else {
 #pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) dma_region(t, c);
+    for (int c = 0; c < NCHUNK; ++c) dma_region(t, c);
+  }
 #pragma unroll
   for (int d = 0; d < PFD; ++d) issue_ring();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   int slot_rd = 0;
   uint4v keep[NPASS][WCB][WPB][2];  // residual tile saved by an earlier conv of the chain (packed fp16, pair16 layout)
+  uint4v hold0[WCB][WPB][2];        // S2, two cout passes: pass 0's t tile while pass 1 still reads the input patches
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
@@ -1423,13 +1490,135 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
     }
 
+    if constexpr (S2) {
+      // ================= stride-2 conv + projection shortcut of the stage, on this tile =================
+      if (patch_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // patches 0 and 1 of this tile (issued a tile ago / in the prologue)
+      asm volatile("s_barrier" ::: "memory");
+      int bS[WPB];  // patch pixel of tap (0, 0) for this lane's output pixels
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) bS[j] = ((pj[j] >> (2 * HL)) * PRS + 2 * ((pj[j] >> HL) & (H - 1))) * PCW + (pj[j] & (H - 1));
+      uint4v hold[WCB][WPB][2];
+      static_for<NPASS>([&](auto kp) {
+        constexpr int ps = decltype(kp)::value;
+        float16v acc[WCB][WPB], accs[WCB][WPB];
+#pragma unroll
+        for (int i = 0; i < WCB; ++i)
+#pragma unroll
+          for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accs[i][j][r] = 0.f; }
+#pragma unroll 1
+        for (int chunk = 0; chunk < NCS; ++chunk) {
+          const int si = ps * NCS + chunk;  // stride-2 step index in this tile
+          issue_ring();
+          if (si >= 1 && si + 1 < NS) patch_dma(t, si + 1);  // into the buffer step si - 1 has finished with
+          {
+            const uint32_t wb = lds0 + ((si & 1) ? SOFF1 : SOFF0) + (wc * WCB) * 1024 + lane16;
+            const uint32_t pb = lds0 + (((si + 1) & 1) ? PBYTES : 0);
+            half8 fa[2][WCB], fb[2][WPB];
+            auto issue = [&](auto ic) {
+              constexpr int tt = decltype(ic)::value, sl = tt & 1;
+              constexpr int te = tt == 9 ? 4 : tt, dy = te / 3, dx = te % 3;  // the 1x1 stride-2 shortcut reads the centre tap's pixel
+              constexpr int off = dy * PCW + (dx == 1 ? H + 1 : dx / 2);
+              static_for<WCB>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                lds_read128<(tt * CBT + i) * 1024>(fa[sl][i], wb);
+              });
+              static_for<WPB>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                const int qS = bS[j] + off;
+                lds_read128<0>(fb[sl][j], pb + qS * (KCS * 2) + ((h ^ ((qS >> 3) & 1)) << 4));
+              });
+            };
+            issue(std::integral_constant<int, 0>{});
+            static_for<TAPS_S>([&](auto ic) {
+              constexpr int tt = decltype(ic)::value, sl = tt & 1;
+              if constexpr (tt + 1 < TAPS_S) issue(std::integral_constant<int, tt + 1>{});
+              lds_wait<(tt + 1 < TAPS_S ? WCB + WPB : 0)>();
+#pragma unroll
+              for (int i = 0; i < WCB; ++i) lds_touch(fa[sl][i]);
+#pragma unroll
+              for (int j = 0; j < WPB; ++j) lds_touch(fb[sl][j]);
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j) {
+                  if constexpr (tt == 9) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], accs[i][j], 0, 0, 0);
+                  else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+                }
+            });
+          }
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next weight step (ring waves) and next patch (patch waves) landed
+          --ahead;
+        }
+        // t = relu(bn1(conv)) -> activation buffer (pass 0 of 2: held until pass 1 has read its patches -- they overlap the buffer);
+        // sc = bn(shortcut) -> residual registers of conv 0
+#pragma unroll
+        for (int i = 0; i < WCB; ++i) {
+          float4v b1[4], bs[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            b1[q] = *(const float4v *)(a.s2_bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+            bs[q] = *(const float4v *)(a.s2_bias_sc + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+          }
+#pragma unroll
+          for (int j = 0; j < WPB; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              half4 ht[2], hc[2];
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  ht[kk][e] = (_Float16)fmaxf(acc[i][j][4 * (2 * qq + kk) + e] * a.s2_scale + b1[2 * qq + kk][e], 0.f);
+                  hc[kk][e] = (_Float16)(accs[i][j][4 * (2 * qq + kk) + e] * a.s2_scale + bs[2 * qq + kk][e]);
+                }
+              keep[ps][i][j][qq] = pair16(hc[0], hc[1]);
+              hold[i][j][qq] = pair16(ht[0], ht[1]);
+            }
+        }
+        auto put_t = [&](int pass) {
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) {
+                const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
+                *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = hold[i][j][qq];
+              }
+        };
+        if constexpr (NPASS == 1) put_t(0);
+        else if constexpr (ps == 0) {
+          // pass 0's t must wait in registers: park it in keep-sized storage of its own
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) hold0[i][j][qq] = hold[i][j][qq];
+        } else {
+          put_t(1);
+#pragma unroll
+          for (int i = 0; i < WCB; ++i)
+#pragma unroll
+            for (int j = 0; j < WPB; ++j)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) hold[i][j][qq] = hold0[i][j][qq];
+          put_t(0);
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
     static_for<NCONV>([&](auto kc) {
       constexpr int cvi = decltype(kc)::value;
       constexpr bool lastc = cvi == NCONV - 1;
       const ChainConv &cv = a.cv[cvi];
       // the two chains there are (host: run_chain): NCONV == 3: conv2(+sc from HBM, saved) -> conv1 -> conv2(+saved tile);
       // NCONV == 2: conv1 -> conv2(+x from HBM); every conv is followed by a ReLU
-      constexpr int RES = NCONV == 3 ? (cvi == 0 ? 1 : cvi == 2 ? 2 : 0) : (cvi == 1 ? 1 : 0);
+      // (S2: conv 0's residual sc is not in HBM but in the registers the stride-2 phase left it in)
+      constexpr int RES = NCONV == 3 ? (cvi == 0 ? (S2 ? 2 : 1) : cvi == 2 ? 2 : 0) : (cvi == 1 ? 1 : 0);
       constexpr bool SAVE = NCONV == 3 && cvi == 0;
       uint4v hold[WCB][WPB][2];  // NPASS == 2: pass 0's activated tile until pass 1 has finished reading the buffer
       static_for<NPASS>([&](auto kp) {
@@ -1451,7 +1640,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
           for (int g = 0; g < NG; ++g) {
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
             // the last K loop has finished reading region chunk-1: the next sample's input may land there
-            if (last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
+            if (!S2 && last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
             if (RES == 1 && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
 #pragma unroll
               for (int i = 0; i < WCB; ++i)
@@ -1544,8 +1733,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
         }
         // every wave is past the last step's barrier
         if constexpr (lastc) {
-          if constexpr (last) {
-            if (has_next) dma_region(t + tstep, NCHUNK - 1);  // nobody reads the activation buffer any more
+          if constexpr (last) {  // nobody reads the activation buffer any more
+            if constexpr (S2) {
+              if (has_next) { patch_dma(t + tstep, 0); patch_dma(t + tstep, 1); }  // both patch buffers of the next tile
+            } else if (has_next) dma_region(t + tstep, NCHUNK - 1);
           }
           float4v bq[WCB][4], bsq[1][4];
 #pragma unroll
@@ -2352,9 +2543,9 @@ template <class K> static hipError_t ensure_big_lds(K kern, DeviceOnce &once) {
   if (e == hipSuccess) once.done(dev);
   return e;
 }
-template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0>
+template <int CIN, int COUT, int STRIDE, int TAPS, bool SC, int KC, int NSPLIT, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int UN, int MINW, bool DMA, int CBP = 0, bool KMAJ = false>
 static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
-  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA, CBP>;
+  auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, TAPS, SC, KC, NSPLIT, WCB, WPB, WAVES_C, WAVES_P, GT, RB, UN, MINW, DMA, CBP, KMAJ>;
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
@@ -2599,8 +2790,10 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
     if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 64, 1, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);
     if (cin == 128 && cout == 128 && stride == 1) return launch_conv_t<128, 128, 1, 9, false, 64, 1, 1, 1, 1, 4, CFG_LAT_GT, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
     if (cin == 256 && cout == 256 && stride == 1) return launch_conv_t<256, 256, 1, 9, false, 64, 1, 1, 1, 1, 4, CFG_LAT_GT, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
-    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4>(a, grid_x, extra_lds, st);
-    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4>(a, grid_x, extra_lds, st);
+    // (k-step-major items: the accumulation order of the whole-stage kernel, see KMAJ)
+    static_assert(CFG_LAT_GT2 == 10, "the stride-2 latency variants take all 10 weight taps of a chunk per step");
+    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4, true>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 1, 1, 1, 1, 4, CFG_LAT_GT2, 2, 10, 1, false, 4, true>(a, grid_x, extra_lds, st);
     return hipErrorInvalidValue;
   }
 #endif
@@ -2650,15 +2843,17 @@ template <class K> static hipError_t launch_chain_t(K kern, DeviceOnce &once, co
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3(threads), lds, st, a);
   return hipGetLastError();
 }
-hipError_t mlt_launch_chain(int c, int h, const ChainArgs &a, int grid_x, hipStream_t st) {
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int grid_x, hipStream_t st) {
   static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel reads the packing of the stand-alone 128->128 / 256->256 layers");
   constexpr int lds = 64 * 1024 + 2 * (CFG_BIG_GT * 4 * 4 * 1024);  // 64 KiB activation + two 48 KiB weight steps = all of the LDS
-  static DeviceOnce once[4];
+  static DeviceOnce once[6];
   if (c == 128 && h == 16) {  // 8 waves x (64 couts x 64 pixels), one sample per workgroup
+    if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[4], a, grid_x, 512, lds, st);
     if (a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[0], a, grid_x, 512, lds, st);
     if (a.nconv == 2) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[1], a, grid_x, 512, lds, st);
   }
   if (c == 256 && h == 8) {   // 8 waves x (64 couts x 32 pixels) x 2 cout passes, two samples per workgroup
+    if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[5], a, grid_x, 512, lds, st);
     if (a.nconv == 3) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[2], a, grid_x, 512, lds, st);
     if (a.nconv == 2) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[3], a, grid_x, 512, lds, st);
   }

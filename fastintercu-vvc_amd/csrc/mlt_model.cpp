@@ -290,6 +290,25 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
       const bool has_sc = (st != 1 || bin != c);  // arch:44-45
       if (!(s == 0 && bi == 0) &&  // layer0.0.conv1 + shortcut live in the composed first layer (m.stem)
           !make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
+      // second packing of the stride-2 conv for the whole-stage kernel: 16-channel chunks, all 10 "taps" of a chunk = one 40 KiB step
+      if (!exact && bi == 0 && s >= 1 && has_sc && B.conv1.taps == 9 && mlt_chain_supported(c, (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1)) {
+        PackedConv &pc = B.conv1_s2c;
+        pc = PackedConv();
+        pc.cin = bin; pc.cout = c; pc.taps = 9; pc.stride = 2; pc.has_sc = true; pc.exact = false;
+        pc.kc = 16; pc.ct = 128; pc.gt = 10;
+        std::snprintf(nm, sizeof nm, "layer%d.%d.conv1.weight", s, bi);
+        const float *w = b.find(nm, (uint64_t)c * bin * 9, err);
+        std::snprintf(nm, sizeof nm, "layer%d.%d.shortcut.0.weight", s, bi);
+        const float *wsc = b.find(nm, (uint64_t)c * bin, err);
+        if (!w || !wsc) return false;
+        std::vector<double> scale, scale_sc;
+        std::snprintf(nm, sizeof nm, "layer%d.%d.bn1", s, bi);
+        fold_scale(b, nm, c, scale, pc.bias, err);
+        std::snprintf(nm, sizeof nm, "layer%d.%d.shortcut.1", s, bi);
+        fold_scale(b, nm, c, scale_sc, pc.bias_sc, err);
+        if (!err.empty()) return false;
+        pack_conv(pc, w, scale, wsc, scale_sc);
+      }
       if (!make(B.conv2, "conv2.weight", "bn2", c, 1, false)) return false;
     }
     cin = c;

@@ -31,6 +31,8 @@ struct PackedConv {
 
 struct Block {
   PackedConv conv1, conv2;  // conv1 carries the projection shortcut when the block has one (arch:44-50)
+  PackedConv conv1_s2c;     // fast arithmetic, stages with a whole-stage kernel (chain_kernel S2): conv1 + shortcut packed again
+                            // for 16-channel chunks and 128-cout tiles (empty otherwise)
 };
 
 struct Head {
