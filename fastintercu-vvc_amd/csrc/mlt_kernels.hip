@@ -1324,10 +1324,16 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   // stride-2 front conv (S2)
   constexpr int CIN = C / 2, HIN = 2 * H, KCS = 16, NCS = CIN / KCS, TAPS_S = 10, NS = S2 ? NPASS * NCS : 0;
   constexpr int NCH = NCONV * NPASS * NCHUNK * NG;                       // chain steps per tile
-  constexpr int WSTEP_S = TAPS_S * CBT * 1024, NPIECE_S = WSTEP_S / 1024, PPWR_S = (NPIECE_S + NWR - 1) / NWR;
+  constexpr int WSTEP_S = TAPS_S * CBT * 1024, NPIECE_S = WSTEP_S / 1024;
   constexpr int PRS = 2 * H + 1, PCW = 2 * H + 1, PPS = PRS * PCW, PPIX = PPS << SPW_L;  // patch rows, columns (H+1 odd + H even), pixels
-  constexpr int PBYTES = (PPIX * KCS * 2 + 1023) / 1024 * 1024, PPIECE = PBYTES / 1024, PPP = (PPIECE + NWP - 1) / NWP;
+  constexpr int PBYTES = (PPIX * KCS * 2 + 1023) / 1024 * 1024, PPIECE = PBYTES / 1024;
   constexpr int SOFF0 = ACT + 8 * 1024, SOFF1 = ACT + WCHUNK + 8 * 1024;  // LDS offsets of the two stride-2 weight steps
+  // patch buffers: three where they fit below the first weight step (8 x 8 maps: 19 KiB patches) -> a patch is requested two steps
+  // before it is read; else two.  Either way the LAST step of a tile reads buffer 0, the only one the first chain step's weights
+  // (landing in [ACT, ACT + WCHUNK) meanwhile) cannot overlap.
+  constexpr int NPB = 3 * PBYTES <= SOFF0 ? 3 : 2, PLA = NPB - 1;
+  auto pbuf = [](int i) { return NPB == 3 ? i % 3 : (i + 1) & 1; };
+  static_assert(!S2 || (NPB == 3 ? (NS - 1) % 3 == 0 : (NS - 1) % 2 == 1), "S2: the last stride-2 step must read patch buffer 0");
   static_assert(!S2 || (SPLIT_ROLES && RB == 2 && NS % 2 == 0 && NCH % 2 == 0 && (NCS - 1) % 2 == 1), "S2: step parities");
   static_assert(!S2 || (2 * PBYTES <= SOFF0 && SOFF0 + WSTEP_S <= ACT + WCHUNK && SOFF1 + WSTEP_S <= 160 * 1024), "S2: LDS layout");
 
@@ -1385,14 +1391,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     if (ring_wave) {
 #endif
       if (s_step) {
-        const char *src = (const char *)a.s2_w + (size_t)r_pos * WSTEP_S;
-        char *dst = smem + ((r_pos & 1) ? SOFF1 : SOFF0);
-#pragma unroll
-        for (int k = 0; k < PPWR_S; ++k) {
-          int pi = wave + k * NWR;
-          pi = pi < NPIECE_S ? pi : NPIECE_S - 1;
-          glds16(src + pi * 1024 + lane16, dst + pi * 1024);
-        }
       } else {
         const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
         const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
@@ -1405,6 +1403,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
         }
       }
     }
+    if (s_step) {  // stride-2 weight steps: every wave issues its share (all waves wait with vmcnt(0) at the end of those steps anyway)
+      const char *src = (const char *)a.s2_w + (size_t)r_pos * WSTEP_S;
+      char *dst = smem + ((r_pos & 1) ? SOFF1 : SOFF0);
+#pragma unroll
+      for (int k = 0; k < (NPIECE_S + NW - 1) / NW; ++k) {
+        const int pi = wave + k * NW;
+        if (pi < NPIECE_S) glds16(src + pi * 1024 + lane16, dst + pi * 1024);
+      }
+    }
     --steps_to_issue;
     ++ahead;
     if (!s_step) {
@@ -1415,13 +1422,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   // ---- S2: input patch of stride-2 step i (16 channels, chunk i % NCS) -> patch buffer (i + 1) & 1 (patch waves).  Patch pixel
   // qS = (sample * PRS + r) * PCW + k holds input pixel (r - 1, k <= H ? 2k - 1 : 2(k - H - 1)); its two 16-byte channel slots are
   // swapped when bit 3 of qS is set (16 consecutive patch pixels span two 256-byte bank rows).  Outside the picture: zero page.
-  auto patch_dma = [&](int tile, int i) {
-    if (!patch_wave) return;
+  auto patch_dma = [&](int tile, int i) {  // every wave issues its share
     const int chunk = i % NCS;
-    char *dst = smem + (((i + 1) & 1) ? PBYTES : 0);
+    char *dst = smem + pbuf(i) * PBYTES;
 #pragma unroll
-    for (int k = 0; k < PPP; ++k) {
-      const int piece = (wave - WP0) + k * NWP;
+    for (int k = 0; k < (PPIECE + NW - 1) / NW; ++k) {
+      const int piece = wave + k * NW;
       if (piece >= PPIECE) break;  // wave-uniform
       const int it = piece * 64 + lane, qS = it >> 1, pos = it & 1;
       const int sl = pos ^ ((qS >> 3) & 1);
@@ -1454,8 +1460,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 
   // ---- prologue ----
   if constexpr (S2) {
-    patch_dma(t, 0);
-    patch_dma(t, 1);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) patch_dma(t, i);
   } else {
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) dma_region(t, c);
@@ -1492,12 +1498,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 
     if constexpr (S2) {
       // ================= stride-2 conv + projection shortcut of the stage, on this tile =================
-      if (patch_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // patches 0 and 1 of this tile (issued a tile ago / in the prologue)
-      asm volatile("s_barrier" ::: "memory");
+      // patches 0 and 1 and the first weight step of this tile (issued a tile ago / in the prologue; every wave has a share)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       int bS[WPB];  // patch pixel of tap (0, 0) for this lane's output pixels
 #pragma unroll
       for (int j = 0; j < WPB; ++j) bS[j] = ((pj[j] >> (2 * HL)) * PRS + 2 * ((pj[j] >> HL) & (H - 1))) * PCW + (pj[j] & (H - 1));
-      uint4v hold[WCB][WPB][2];
+      auto put_t = [&](int pass, int i, int j, int qq, uint4v w) {  // this lane: channels cb .. cb+7 of pixel pj[j] -> activation buffer
+        const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
+        *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = w;
+      };
       static_for<NPASS>([&](auto kp) {
         constexpr int ps = decltype(kp)::value;
         float16v acc[WCB][WPB], accs[WCB][WPB];
@@ -1510,11 +1519,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll 1
         for (int chunk = 0; chunk < NCS; ++chunk) {
           const int si = ps * NCS + chunk;  // stride-2 step index in this tile
+          if (si >= 1 && si + PLA < NS) patch_dma(t, si + PLA);  // (HBM: first) into the buffer step si - 1 has finished with
           issue_ring();
-          if (si >= 1 && si + 1 < NS) patch_dma(t, si + 1);  // into the buffer step si - 1 has finished with
           {
             const uint32_t wb = lds0 + ((si & 1) ? SOFF1 : SOFF0) + (wc * WCB) * 1024 + lane16;
-            const uint32_t pb = lds0 + (((si + 1) & 1) ? PBYTES : 0);
+            const uint32_t pb = lds0 + pbuf(si) * PBYTES;
             half8 fa[2][WCB], fb[2][WPB];
             auto issue = [&](auto ic) {
               constexpr int tt = decltype(ic)::value, sl = tt & 1;
@@ -1574,38 +1583,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                   hc[kk][e] = (_Float16)(accs[i][j][4 * (2 * qq + kk) + e] * a.s2_scale + bs[2 * qq + kk][e]);
                 }
               keep[ps][i][j][qq] = pair16(hc[0], hc[1]);
-              hold[i][j][qq] = pair16(ht[0], ht[1]);
+              const uint4v wt = pair16(ht[0], ht[1]);
+              if constexpr (NPASS == 2 && ps == 0) hold0[i][j][qq] = wt;  // pass 1 still reads the patches, which overlap the buffer
+              else put_t(ps, i, j, qq, wt);
             }
         }
-        auto put_t = [&](int pass) {
+        if constexpr (NPASS == 2 && ps == 1) {
 #pragma unroll
           for (int i = 0; i < WCB; ++i)
 #pragma unroll
             for (int j = 0; j < WPB; ++j)
 #pragma unroll
-              for (int qq = 0; qq < 2; ++qq) {
-                const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
-                *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = hold[i][j][qq];
-              }
-        };
-        if constexpr (NPASS == 1) put_t(0);
-        else if constexpr (ps == 0) {
-          // pass 0's t must wait in registers: park it in keep-sized storage of its own
-#pragma unroll
-          for (int i = 0; i < WCB; ++i)
-#pragma unroll
-            for (int j = 0; j < WPB; ++j)
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq) hold0[i][j][qq] = hold[i][j][qq];
-        } else {
-          put_t(1);
-#pragma unroll
-          for (int i = 0; i < WCB; ++i)
-#pragma unroll
-            for (int j = 0; j < WPB; ++j)
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq) hold[i][j][qq] = hold0[i][j][qq];
-          put_t(0);
+              for (int qq = 0; qq < 2; ++qq) put_t(0, i, j, qq, hold0[i][j][qq]);
         }
       });
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1735,7 +1724,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
         if constexpr (lastc) {
           if constexpr (last) {  // nobody reads the activation buffer any more
             if constexpr (S2) {
-              if (has_next) { patch_dma(t + tstep, 0); patch_dma(t + tstep, 1); }  // both patch buffers of the next tile
+              if (has_next) {  // all patch buffers of the next tile
+#pragma unroll
+                for (int i = 0; i < NPB; ++i) patch_dma(t + tstep, i);
+              }
             } else if (has_next) dma_region(t + tstep, NCHUNK - 1);
           }
           float4v bq[WCB][4], bsq[1][4];

@@ -21,9 +21,12 @@ def per_kernel(path, counter):
         if m:
             cin, cout, st = map(int, m.groups())
             name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")
-        elif (mc := re.search(r"chain_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, (\d+)", k)):
-            c, hl, nconv = map(int, mc.groups())
-            name = f"chain{nconv}_s1_{c}_h{1 << hl}(conv2+conv1+conv2)"
+        elif (mc := re.search(r"chain_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, (\d+), \w+(?:, (\w+))?>", k)):
+            c, hl, nconv = map(int, mc.groups()[:3])
+            if mc.group(4) == "true":
+                name = f"stage_{c}_h{1 << hl}(s2+sc,conv2,conv1,conv2)"
+            else:
+                name = f"chain{nconv}_s1_{c}_h{1 << hl}(conv2+conv1+conv2)"
         elif "stem_block_kernel" in k:
             name = "stem+block_s2_2to32_h64(layer0.0)"
         elif "block32_kernel" in k:
