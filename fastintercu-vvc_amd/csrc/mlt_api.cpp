@@ -114,6 +114,7 @@ struct mlt_ctx {
   size_t guard_slot_bytes = 0;
   int guard_cap_n = 0, guard_cap_nl = 0;
   int32_t *guard_host = nullptr;  // pinned: two counters
+  hipEvent_t ev_guard = nullptr;  // "count of flagged CUs has landed" (device-pointer entry)
   char *gstage = nullptr;
   size_t gstage_bytes = 0;
   std::string err;
@@ -665,7 +666,19 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   int rc = guard_slot(ctx, 0, n, st.model.n_logits, &g);
   if (rc) return rc;
   if ((rc = run_guarded_async(ctx, st, n, pl, d_poc, d_qp, d_split, d_logits, g))) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // Wait for the count by polling an event: hipStreamSynchronize sleeps on an interrupt (tens of microseconds of idle GPU before
+  // the caller's next batch can be enqueued); MLT_GUARD_BLOCKING_WAIT=1 restores it (frees the host core for the ~ms the batch takes).
+  static const bool blocking = std::getenv("MLT_GUARD_BLOCKING_WAIT") != nullptr;
+  if (blocking) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  else {
+    if (!ctx->ev_guard) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_guard, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_guard, ctx->stream));
+    hipError_t e;
+    while ((e = hipEventQuery(ctx->ev_guard)) == hipErrorNotReady) {
+      for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+    }
+    HIP_TRY(ctx, e);
+  }
   const int k = *g.h_count;
   if (k < 0 || k > n) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
   return k ? guard_fixup_async(ctx, st, k, pl, d_poc, d_qp, d_split, d_logits, g) : MLT_OK;
@@ -896,6 +909,7 @@ void mlt_shutdown(mlt_ctx *ctx) {
   if (ctx->guard_dev) (void)hipFree(ctx->guard_dev);
   if (ctx->gstage) (void)hipFree(ctx->gstage);
   if (ctx->guard_host) (void)hipHostFree(ctx->guard_host);
+  if (ctx->ev_guard) (void)hipEventDestroy(ctx->ev_guard);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
