@@ -247,6 +247,7 @@ struct ConvIO {
   const void *res = nullptr;  // residual added before the ReLU
   float *gap = nullptr;       // GAP partial sums
   bool relu = false;
+  bool y_c16 = false;         // main output chunk-major (ConvArgs.y_c16)
   size_t x_lo = 0, y_lo = 0, res_lo = 0, ysc_lo = 0;  // exact mode: byte offsets hi plane -> lo plane
 };
 
@@ -255,7 +256,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   *hout_out = hout;
   ConvArgs a{};
   a.x = io.x; a.y = io.y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = io.res; a.n = n; a.relu = io.relu ? 1 : 0;
-  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale;
+  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale; a.y_c16 = io.y_c16 ? 1 : 0;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
@@ -399,10 +400,11 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
 // s2_in != NULL: the stage's stride-2 conv + shortcut run inside the same launch from the stage input s2_in ([n][2h][2h][c/2]);
 // t / sc are then unused.
 int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap,
-               const void *s2_in = nullptr) {
+               const void *s2_in = nullptr, bool x_c16 = false, bool y_c16 = false) {
   const int c = B0.conv2.cout;
   ChainArgs a{};
   a.x = s2_in ? s2_in : t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n; a.zero = ctx->zero_page;
+  a.x_c16 = x_c16 ? 1 : 0; a.y_c16 = y_c16 ? 1 : 0;
   const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
   for (int k = 0; k < 3; ++k) {
     a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
@@ -462,6 +464,21 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   const void *cur = nullptr;
   int h = S;
   HeadArgs ha{};
+  // Which stages run as chain / whole-stage launches (fast arithmetic, large launches; small ones keep the per-conv latency
+  // variants: a chain runs its convs one after the other on n workgroups).  Asked for stage s AND for stage s + 1: a stage
+  // whose successor is a whole-stage kernel writes its output chunk-major (ConvArgs.y_c16).
+  static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+  static const bool no_chain_s2 = std::getenv("MLT_NO_CHAIN_S2") != nullptr;
+  static const bool no_c16 = std::getenv("MLT_NO_C16") != nullptr;
+  static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+  auto wants_chain = [&](int s, int h_in) -> bool {
+    if (s <= 0 || s >= m.n_stages || m.exact || no_chain) return false;
+    const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
+    const mlt::PackedConv &c2 = m.blocks[s][0].conv2;
+    return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && c2.ct == 128 && c2.gt == 3 && (long)n * ho * ho > chain_min_px;
+  };
+  auto wants_s2 = [&](int s, int h_in) -> bool { return wants_chain(s, h_in) && !no_chain_s2 && m.blocks[s][0].conv1_s2c.d_w != nullptr; };
+  bool cur_c16 = false;  // layout of `cur`
   for (int s = 0; s < m.n_stages; ++s) {
     int hout = h, h2;
     const bool last = s == m.n_stages - 1;
@@ -491,21 +508,19 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       hout = ho;
       if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
     } else {
-      static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-      static const bool no_chain_s2 = std::getenv("MLT_NO_CHAIN_S2") != nullptr;
-      // (small launches keep the per-conv latency variants: a chain runs its convs one after the other on n workgroups)
-      static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
-      const bool chain = s > 0 && !m.exact && !no_chain && mlt_chain_supported(m.planes[s], ho) && B0.conv2.taps == 9 && B0.conv2.kc == 64 &&
-                         B0.conv2.ct == 128 && B0.conv2.gt == 3 && (long)n * ho * ho > chain_min_px;
-      const bool chain_s2 = chain && !no_chain_s2 && B0.conv1_s2c.d_w != nullptr;  // the stride-2 conv + shortcut join the launch
+      const bool chain = wants_chain(s, h);
+      const bool chain_s2 = wants_s2(s, h);  // the stride-2 conv + shortcut join the launch
       if (s == 0) {
         hout = ho;
         if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if (chain_s2) hout = ho;
       else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
-        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr))) return rc;
+        const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
+        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
+                             cur_c16, out_c16))) return rc;
         cur = outs[s];
+        cur_c16 = out_c16;
         h = hout;
         const int hd = s - 1;
         ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
@@ -533,8 +548,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     io = ConvIO();
     io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
     io.x_lo = io.y_lo = io.res_lo = lo_st;
+    io.y_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
     if ((rc = run_conv(ctx, B1.conv2, n, hout, io, &h2))) return rc;
     cur = outs[s];
+    cur_c16 = io.y_c16;
     h = hout;
     if (s >= 1) {
       const int hd = s - 1;

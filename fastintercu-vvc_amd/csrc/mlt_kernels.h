@@ -21,6 +21,9 @@ struct ConvArgs {
   uint32_t pw_magic, ph_magic, rp_magic; // ceil(2^32 / d), d >= 2
   int patch_bytes;             // LDS bytes reserved for the patch (multiple of 1024)
   int relu;
+  int y_c16;                   // 1: y is written chunk-major, [n][COUT/16][Hout*Hout][16] -- the layout the next stage's whole-stage
+                               // kernel stages its 16-channel input patches from (contiguous 32-byte pixels instead of 32-byte pieces
+                               // of 128/256-byte NHWC pixels: measured 2.2x HBM over-fetch on those)
   float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
   // SC variant: second output = bn(conv1x1_stride2(x)) (projection shortcut, arch:44-50)
   void *y_sc;
@@ -91,6 +94,8 @@ struct ChainArgs {
   ChainConv cv[3];
   int nconv;           // 2 or 3
   void *y;             // [n][H][H][C] fp16 output of the last conv, or NULL (only the GAP sums are needed)
+  int y_c16;           // y chunk-major (ConvArgs.y_c16)
+  int x_c16;           // S2: the stage input x is chunk-major
   float *gap;          // fp32 GAP partial sums of the last conv's output [n][gap_slots][C], or NULL
   int gap_slots, gap_l;
   int n;

@@ -210,7 +210,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
         // every lane takes part in the swaps; only valid pixels store
         if (a.y) {
           const uint4v w = pair16(hq[2 * qq], hq[2 * qq + 1]);
-          if (ok) *(uint4v *)((_Float16 *)a.y + o16 + 16 * qq) = w;
+          if (a.y_c16) {  // chunk-major: [n][COUT / 16][HW][16]; this lane holds channels 8h .. 8h+7 of chunk (cbase + 16 qq) / 16
+            const int op = ok ? opix[j] : 0, hw_l = 2 * a.hout_l, nn = op >> hw_l, pix = op & ((1 << hw_l) - 1);
+            const int chunk = (ctile * CT + (wc * WCB + i) * 32 + 16 * qq) >> 4;
+            if (ok) *(uint4v *)((_Float16 *)a.y + ((((size_t)nn * (COUT / 16) + chunk) << hw_l) + pix) * 16 + 8 * h) = w;
+          } else if (ok) *(uint4v *)((_Float16 *)a.y + o16 + 16 * qq) = w;
           if constexpr (NSPLIT == 2) {
             const uint4v wl = pair16(hl[2 * qq], hl[2 * qq + 1]);
             if (ok) *(uint4v *)((char *)((_Float16 *)a.y + o16 + 16 * qq) + a.y_lo_off) = wl;
@@ -1436,8 +1440,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       int n = (tile << SPW_L) + sm;
       n = n < a.n ? n : a.n - 1;
       const bool live = qS < PPIX && ri >= 0 && ri < HIN && ci >= 0 && ci < HIN;
-      const char *src = live ? (const char *)a.x + ((((size_t)n * HIN + ri) * HIN + ci) * CIN + chunk * KCS + sl * 8) * 2
-                             : (const char *)a.zero + ((((int)blockIdx.x * 64 * NW + tid) * 16) & 0xFFF0);
+      const size_t off = a.x_c16 ? ((((size_t)n * NCS + chunk) * HIN + ri) * HIN + ci) * KCS + sl * 8           // [n][CIN/16][HIN*HIN][16]
+                                 : (((size_t)n * HIN + ri) * HIN + ci) * CIN + chunk * KCS + sl * 8;           // NHWC
+      const char *src = live ? (const char *)a.x + off * 2 : (const char *)a.zero + ((((int)blockIdx.x * 64 * NW + tid) * 16) & 0xFFF0);
       glds16(src, dst + piece * 1024);
     }
   };
@@ -1737,6 +1742,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
           ConvArgs ea{};
           ea.y = a.y; ea.gap = a.gap; ea.gap_slots = a.gap_slots; ea.gap_l = a.gap_l; ea.acc_scale = cv.acc_scale; ea.relu = 1;
+          ea.y_c16 = a.y_c16; ea.hout_l = HL;
           ea.res = RES ? (const void *)a.x : nullptr;  // non-NULL = "add resv"
           float16v acc_sc[1][1];
           uint4v resl[1][1][2];
