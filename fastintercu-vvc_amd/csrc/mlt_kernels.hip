@@ -1905,6 +1905,8 @@ __global__ __launch_bounds__(512) void block32_kernel(const Block32Args a) {
     b2r[q] = *(const float4v *)(a.bias2 + 4 * h + 8 * q);
   }
 
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { asm volatile("" ::"v"(b1r[q])); asm volatile("" ::"v"(b2r[q])); }  // wait for the biases HERE, not inside the tile loop (see stem_block_kernel)
   int t = blockIdx.x;
   if (t < ntiles) issue_patch(t);
   PH_DECL;
@@ -2191,6 +2193,13 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
   for (int k = 0; k < 5; ++k) am[k] = *(const half8 *)((const char *)a.w + k * 1024 + lane * 16);
 #pragma unroll
   for (int k = 0; k < 2; ++k) as[k] = *(const half8 *)((const char *)a.w + (5 + k) * 1024 + lane * 16);
+  // A first use inside the tile loop would make the compiler wait for these loads THERE, with s_waitcnt vmcnt(0) (it cannot
+  // count across the back edge) -- draining the next tile's raw-plane prefetch every iteration, i.e. exposing the HBM latency
+  // the prefetch exists to hide.  Using the registers here moves that wait in front of the loop.
+#pragma unroll
+  for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(am[k]));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) asm volatile("" ::"v"(as[k]));
   // biases in LDS (this kernel is register-bound: 48 VGPRs of biases meant spills inside the block loops):
   // BL[0..31] = bias of conv1 (bn1), BL[32..63] = bias of conv2 (bn2) + bias of the shortcut, which are only ever added together
   float *BL = (float *)(W2 + 18 * 1024);
