@@ -2295,17 +2295,22 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
       float16v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // all 20 gathered dwords of the block first, then the five MFMAs back to back: interleaved (4 reads, full wait, 1 MFMA) the
+      // LDS latency was exposed five times per block with the matrix pipe idle in between
+      half8 bk[5];
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) {
-        half8 b;
-        uint32_t *bw = (uint32_t *)&b;
+        uint32_t *bw = (uint32_t *)&bk[ks];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (ks < 3) bw[e] = raw[o + (h ? main_off(8 * ks + 4 + e) : main_off(8 * ks + e))];
           else { const uint32_t v0 = slot_val(8 * ks + e), v1 = slot_val(8 * ks + 4 + e); bw[e] = h ? v1 : v0; }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ks], b, acc, 0, 0, 0);
       }
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) asm volatile("" : "+v"(bk[ks]));  // keeps the loads above the first MFMA
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ks], bk[ks], acc, 0, 0, 0);
       const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;  // outside: conv2's zero padding
       // (16-byte paired stores and row-wise blocks as in block32_kernel were measured slower here: the kernel sits at 256 VGPRs)
       if (ok) {

@@ -11,8 +11,9 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "swz_old": ["CFG_CHAIN_SWZ16=0"],
-    "ko_mask": ["KO_CH_MASK"],
+    "spread2": ["CFG_DMA_SPREAD=2"],
+    "spread3": ["CFG_DMA_SPREAD=3"],
+    "spread4": ["CFG_DMA_SPREAD=4"],
     "base_b": [],
 }
 
