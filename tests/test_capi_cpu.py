@@ -63,3 +63,36 @@ def test_null_ctx_calls_are_errors_not_crashes(lib):
     assert lib.mlt_predict_batch_device(None, 1, 128, None, None, None, None, None, None) == 1
     lib.mlt_shutdown(None)
     lib.mlt_free_pinned(None)
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` outside torchrun must start N ranks as a CHILD process (never exec, nothing GPU-related touched
+    first), relay rank 0's single JSON line and return the child's exit code; inside torchrun (WORLD_SIZE set) it must not."""
+    import importlib
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "m", "n_gpus": 4}\n')
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse_args()
+    assert bench.launch_ranks(args) == 0
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "n_gpus": 4}' and "noise" in out.err
+    # a failing child (or a child that printed no / several JSON lines) is a failure of the command, never a 1-GPU fallback
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="no json here\n"))
+    assert bench.launch_ranks(args) != 0
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=7, stdout='{"a": 1}\n'))
+    assert bench.launch_ranks(args) == 7
