@@ -400,7 +400,7 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
 // s2_in != NULL: the stage's stride-2 conv + shortcut run inside the same launch from the stage input s2_in ([n][2h][2h][c/2]);
 // t / sc are then unused.
 int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap,
-               const void *s2_in = nullptr, bool x_c16 = false, bool y_c16 = false) {
+               const void *s2_in = nullptr, bool x_c16 = false, bool y_c16 = false, void *b0_hbm = nullptr) {
   const int c = B0.conv2.cout;
   ChainArgs a{};
   a.x = s2_in ? s2_in : t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n; a.zero = ctx->zero_page;
@@ -410,6 +410,9 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
     a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
   }
   a.cv[0].res_mode = s2_in ? 2 : 1; a.cv[0].res = sc; a.cv[0].save = 1; a.cv[2].res_mode = 2;
+  if (c == 64) {  // no room for b0 in registers: conv 0 writes it to HBM (b0_hbm), the last conv reads it back as its residual
+    a.cv[0].save = 0; a.cv[0].y = b0_hbm; a.cv[2].res_mode = 1; a.cv[2].res = b0_hbm;
+  }
   if (s2_in) {
     const mlt::PackedConv &p2 = B0.conv1_s2c;
     a.s2_w = p2.d_w; a.s2_bias = p2.d_bias; a.s2_bias_sc = p2.d_bias_sc; a.s2_scale = p2.acc_scale;
@@ -475,7 +478,11 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     if (s <= 0 || s >= m.n_stages || m.exact || no_chain) return false;
     const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
     const mlt::PackedConv &c2 = m.blocks[s][0].conv2;
-    return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && c2.ct == 128 && c2.gt == 3 && (long)n * ho * ho > chain_min_px;
+    // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave) is correct and bit-identical but NOT faster
+    // as built: 1.50 ms against 3 x 0.39 ms (452 B of scratch per lane at the 256-VGPR cap, next-sample input DMA exposed) -- opt-in.
+    static const bool chain64 = std::getenv("MLT_CHAIN64") != nullptr;
+    const bool packing_ok = m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3);  // what chain_kernel<C> streams
+    return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
   auto wants_s2 = [&](int s, int h_in) -> bool { return wants_chain(s, h_in) && !no_chain_s2 && m.blocks[s][0].conv1_s2c.d_w != nullptr; };
   bool cur_c16 = false;  // layout of `cur`
@@ -518,7 +525,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
         if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
-                             cur_c16, out_c16))) return rc;
+                             cur_c16, out_c16, pool[2]))) return rc;
         cur = outs[s];
         cur_c16 = out_c16;
         h = hout;

@@ -82,6 +82,8 @@ struct ChainConv {
   int res_mode;        // 0 none, 1 from `res` (HBM, same layout as the output), 2 from the tile saved by an earlier conv
   int save;            // 1: keep this conv's activated output tile in registers as a later conv's residual
   const void *res;
+  void *y;             // non-final conv: also write the activated output to HBM (NHWC) -- the later residual when the chain does
+                       // not keep it in registers (64-channel stage: 128 accumulator registers leave no room)
 };
 struct ChainArgs {
   const void *x;       // [n][H][H][C] fp16: input of the first conv; S2 variant: the STAGE input [n][2H][2H][C/2]
@@ -102,6 +104,7 @@ struct ChainArgs {
 };
 hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int grid_x, hipStream_t st);
 bool mlt_chain_supported(int c, int h);
+bool mlt_stage_supported(int c, int h);  // ... including the stage's stride-2 conv + shortcut (S2 variant)
 
 struct HeadArgs {
   const float *gap[MLT_MAX_HEADS_K];  // GAP partial sums [n][slots][C] fp32 (written by the stage's last conv)

@@ -1308,7 +1308,11 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
 //     40 KiB ring step.  t goes straight into the activation buffer, sc into the residual registers: neither touches HBM.
 //     LDS during this phase: patches [0, 2 x PBYTES), ring steps at ACT + 8 KiB and ACT + WCHUNK + 8 KiB -- chosen so that
 //     the first chain step can be prefetched during the last stride-2 step and vice versa (see the hazards at issue_ring).
-template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false>
+//   * KEEP = false (64 channels @ 32 x 32: a whole sample is 128 KiB, weights stream 1 tap = 8 KiB per step through a 4-deep ring,
+//     a wave owns 64 couts x 128 pixels = 8 accumulators = 128 VGPRs): no room to keep b0 in registers -- conv 0 also writes it
+//     to HBM (ChainConv.y) and the last conv reads it back (L2-hot) as an ordinary residual, both loaded AFTER the last step's
+//     MFMA loop.  One channel chunk only, so the next sample's input can be fetched only after the last step of the last conv.
+template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false, bool KEEP = true>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
   constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = TAPS / GT;
   constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NPASS = C / CT, NW = WAVES_C * WAVES_P;
@@ -1321,8 +1325,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   constexpr int PPWR = (NPIECE + NWR - 1) / NWR;
   constexpr int REGION = M * KC * 2, ACT = NCHUNK * REGION, RPIECE = REGION / 1024, PPR = (RPIECE + NWP - 1) / NWP;
   static_assert(ACT + NBUF * WCHUNK <= 160 * 1024, "LDS");
-  static_assert(RB == 2 || RB == 3, "ring depth");
+  static_assert(RB >= 2 && RB <= 4, "ring depth");
   static_assert(SPLIT_ROLES || RB == 2, "unified issue waits with vmcnt(0)");
+  static_assert(!S2 || KEEP, "the whole-stage variant keeps sc / b0 in registers");
   static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
   static_assert(((GT * KS - 1) * CBT + WCB - 1) * 1024 < 65536, "fragment offsets are ds_read immediates");
   // stride-2 front conv (S2)
@@ -1386,6 +1391,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   //   overlaps only patch buffer 1's tail and SOFF0, both last read one step earlier.
   int steps_to_issue = ((ntiles - 1 - t) / tstep + 1) * (NS + NCH);
   int r_pos = 0, r_cv = 0, r_ps = 0, r_ci = 0, r_gi = 0, ahead = 0;  // r_pos: position in the tile's NS + NCH steps
+  int slot_wr = 0;  // ring slot of the next chain step (S2: NCH is even and RB == 2, so every tile starts at slot 0 again)
   auto issue_ring = [&]() {
     if (steps_to_issue <= 0) return;
     const bool s_step = S2 && r_pos < NS;
@@ -1398,7 +1404,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       } else {
         const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
         const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
-        char *dst = ring + ((r_pos - NS) & 1) * WCHUNK;
+        char *dst = ring + slot_wr * WCHUNK;
 #pragma unroll
         for (int k = 0; k < PPWR; ++k) {
           int pi = wave + k * NWR;
@@ -1419,6 +1425,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     --steps_to_issue;
     ++ahead;
     if (!s_step) {
+      if (++slot_wr == NBUF) slot_wr = 0;
       if (++r_gi == NG) { r_gi = 0; if (++r_ci == NCHUNK) { r_ci = 0; if (++r_ps == NPASS) { r_ps = 0; if (++r_cv == NCONV) r_cv = 0; } } }
     }
     if (++r_pos == NS + NCH) r_pos = 0;
@@ -1501,6 +1508,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
     }
 
+    if constexpr (!S2 && NCHUNK == 1) {  // single-region buffer: the next sample's input was requested only after the previous tile's last step
+      if (patch_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+    }
     if constexpr (S2) {
       // ================= stride-2 conv + projection shortcut of the stage, on this tile =================
       // patches 0 and 1 and the first weight step of this tile (issued a tile ago / in the prologue; every wave has a share)
@@ -1612,8 +1623,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       // the two chains there are (host: run_chain): NCONV == 3: conv2(+sc from HBM, saved) -> conv1 -> conv2(+saved tile);
       // NCONV == 2: conv1 -> conv2(+x from HBM); every conv is followed by a ReLU
       // (S2: conv 0's residual sc is not in HBM but in the registers the stride-2 phase left it in)
-      constexpr int RES = NCONV == 3 ? (cvi == 0 ? (S2 ? 2 : 1) : cvi == 2 ? 2 : 0) : (cvi == 1 ? 1 : 0);
-      constexpr bool SAVE = NCONV == 3 && cvi == 0;
+      // (KEEP = false: b0 goes through HBM instead of the registers: conv 0 stores it, the last conv loads it as cv.res)
+      constexpr int RES = NCONV == 3 ? (cvi == 0 ? (S2 ? 2 : 1) : cvi == 2 ? (KEEP ? 2 : 1) : 0) : (cvi == 1 ? 1 : 0);
+      constexpr bool SAVE = KEEP && NCONV == 3 && cvi == 0;
+      constexpr bool RES_LATE = !KEEP;  // residual loads after the last step's MFMA loop (the fragment registers are free then)
       uint4v hold[WCB][WPB][2];  // NPASS == 2: pass 0's activated tile until pass 1 has finished reading the buffer
       static_for<NPASS>([&](auto kp) {
         constexpr int ps = decltype(kp)::value;
@@ -1635,7 +1648,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
             // the last K loop has finished reading region chunk-1: the next sample's input may land there
             if (!S2 && last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
-            if (RES == 1 && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
+            if (RES == 1 && !RES_LATE && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
 #pragma unroll
               for (int i = 0; i < WCB; ++i)
 #pragma unroll
@@ -1704,14 +1717,34 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                   for (int j = 0; j < WPB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], bm[j], acc[i][j], 0, 0, 0);
               });
             }
+            if constexpr (RES == 1 && RES_LATE) {
+              // (defined in every iteration by the empty asm: not live across any step's MFMA loop, only from here to the epilogue)
+#pragma unroll
+              for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                for (int j = 0; j < WPB; ++j)
+#pragma unroll
+                  for (int qq = 0; qq < 2; ++qq) asm volatile("" : "=v"(resv[i][j][qq]));
+              if (chunk == NCHUNK - 1 && g == NG - 1) {
+#pragma unroll
+                for (int i = 0; i < WCB; ++i)
+#pragma unroll
+                  for (int j = 0; j < WPB; ++j) {
+                    const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * C + ps * CT + (wc * WCB + i) * 32 + 8 * h;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)cv.res + o + 16 * qq);
+                  }
+              }
+            }
             // ---- end of step: next ring step landed (ring waves); next sample's regions landed (patch waves) where the
             // following step reads them ----
             if constexpr (SPLIT_ROLES) {
-              if (ring_wave) {
-                if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
+              if (ring_wave) {  // the step after this one has landed; the ahead - 2 younger ones may still fly
+                if (PFD >= 3 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPWR) : "memory");
+                else if (PFD >= 2 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWR) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               } else {
-                const bool before_next_sample = last && chunk == NCHUNK - 1 && g == NG - 1;                 // regions 0 .. NCHUNK-2
+                const bool before_next_sample = NCHUNK > 1 && last && chunk == NCHUNK - 1 && g == NG - 1;   // regions 0 .. NCHUNK-2
                 const bool before_last_region = cvi == 0 && ps == 0 && chunk == NCHUNK - 2 && g == NG - 1;  // region NCHUNK-1
                 if (before_next_sample || before_last_region) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               }
@@ -1782,6 +1815,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                   }
                 const uint4v w = pair16(hq[0], hq[1]);
                 if constexpr (SAVE) keep[ps][i][j][qq] = w;
+                if constexpr (!KEEP) {  // the later residual goes through HBM
+                  if (cv.y && opix[j] >= 0) *(uint4v *)((_Float16 *)cv.y + (size_t)opix[j] * C + ps * CT + (wc * WCB + i) * 32 + 8 * h + 16 * qq) = w;
+                }
                 if constexpr (ps == NPASS - 1) put(ps, i, j, qq, w);
                 else hold[i][j][qq] = w;
               }
@@ -2842,7 +2878,8 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
 
 // fused chain kernels: (channels, map height) -> instantiation.  128@16: one sample per 16-wave workgroup, weights packed for
 // 128-cout tiles / 64-channel chunks / 3 taps per step (the stand-alone layer's packing).
-bool mlt_chain_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }
+bool mlt_chain_supported(int c, int h) { return (c == 64 && h == 32) || (c == 128 && h == 16) || (c == 256 && h == 8); }
+bool mlt_stage_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }  // whole-stage (S2) variant
 
 #ifndef CFG_CHAIN_FD     // fragment prefetch distance of chain_kernel (items)
 #define CFG_CHAIN_FD 2
@@ -2859,6 +2896,11 @@ hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int 
   static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel reads the packing of the stand-alone 128->128 / 256->256 layers");
   constexpr int lds = 64 * 1024 + 2 * (CFG_BIG_GT * 4 * 4 * 1024);  // 64 KiB activation + two 48 KiB weight steps = all of the LDS
   static DeviceOnce once[6];
+  if (c == 64 && h == 32 && a.nconv == 3 && !with_s2) {  // 8 waves x (64 couts x 128 pixels), one 128 KiB sample per workgroup, 4 x 8 KiB weight ring
+    static_assert(CFG_64_WCB == 2 && CFG_64_WC == 1 && CFG_64_GT == 9, "chain_kernel<64,...> reads the packing of the stand-alone 64->64 layer");
+    static DeviceOnce once64;
+    return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 4, 1, 2, 3, true, false, false>, once64, a, grid_x, 512, 128 * 1024 + 4 * 8 * 1024, st);
+  }
   if (c == 128 && h == 16) {  // 8 waves x (64 couts x 64 pixels), one sample per workgroup
     if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[4], a, grid_x, 512, lds, st);
     if (a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[0], a, grid_x, 512, lds, st);

@@ -291,7 +291,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
       if (!(s == 0 && bi == 0) &&  // layer0.0.conv1 + shortcut live in the composed first layer (m.stem)
           !make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
       // second packing of the stride-2 conv for the whole-stage kernel: 16-channel chunks, all 10 "taps" of a chunk = one 40 KiB step
-      if (!exact && bi == 0 && s >= 1 && has_sc && B.conv1.taps == 9 && mlt_chain_supported(c, (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1)) {
+      if (!exact && bi == 0 && s >= 1 && has_sc && B.conv1.taps == 9 && mlt_stage_supported(c, (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1)) {
         PackedConv &pc = B.conv1_s2c;
         pc = PackedConv();
         pc.cin = bin; pc.cout = c; pc.taps = 9; pc.stride = 2; pc.has_sc = true; pc.exact = false;
