@@ -21,9 +21,11 @@ def per_kernel(path, counter):
         if m:
             cin, cout, st = map(int, m.groups())
             name = f"conv3x3_s{st}_{cin}to{cout}_h{H_BY_COUT[cout]}" + ("+sc" if st == 2 else "")
-        elif (mc := re.search(r"chain_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, \d+, (\d+), \w+(?:, (\w+))?>", k)):
-            c, hl, nconv = map(int, mc.groups()[:3])
-            if mc.group(4) == "true":
+        elif (mc := re.search(r"chain_kernel<([^>]*)>", k)):
+            # <C, HL, SPW_L, WCB, WPB, WAVES_C, WAVES_P, GT, RB, FD, MINW, NCONV, SPLIT_ROLES, S2, KEEP>
+            targs = [x.strip() for x in mc.group(1).split(",")]
+            c, hl, nconv = int(targs[0]), int(targs[1]), int(targs[11])
+            if len(targs) > 13 and targs[13] == "true":
                 name = f"stage_{c}_h{1 << hl}(s2+sc,conv2,conv1,conv2)"
             else:
                 name = f"chain{nconv}_s1_{c}_h{1 << hl}(conv2+conv1+conv2)"
