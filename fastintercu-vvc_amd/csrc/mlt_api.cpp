@@ -248,6 +248,7 @@ struct ConvIO {
   float *gap = nullptr;       // GAP partial sums
   bool relu = false;
   bool y_c16 = false;         // main output chunk-major (ConvArgs.y_c16)
+  bool ysc_c16 = false;       // shortcut output chunk-major (ConvArgs.ysc_c16)
   size_t x_lo = 0, y_lo = 0, res_lo = 0, ysc_lo = 0;  // exact mode: byte offsets hi plane -> lo plane
 };
 
@@ -256,7 +257,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   *hout_out = hout;
   ConvArgs a{};
   a.x = io.x; a.y = io.y; a.w = pc.d_w; a.bias = pc.d_bias; a.res = io.res; a.n = n; a.relu = io.relu ? 1 : 0;
-  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale; a.y_c16 = io.y_c16 ? 1 : 0;
+  a.y_sc = io.y_sc; a.bias_sc = pc.d_bias_sc; a.acc_scale = pc.acc_scale; a.y_c16 = io.y_c16 ? 1 : 0; a.ysc_c16 = io.ysc_c16 ? 1 : 0;
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
@@ -400,11 +401,11 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
 // s2_in != NULL: the stage's stride-2 conv + shortcut run inside the same launch from the stage input s2_in ([n][2h][2h][c/2]);
 // t / sc are then unused.
 int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, int h, const void *t, const void *sc, void *y, float *gap,
-               const void *s2_in = nullptr, bool x_c16 = false, bool y_c16 = false, void *b0_hbm = nullptr) {
+               const void *s2_in = nullptr, bool x_c16 = false, bool y_c16 = false, void *b0_hbm = nullptr, bool sc_c16 = false) {
   const int c = B0.conv2.cout;
   ChainArgs a{};
   a.x = s2_in ? s2_in : t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n; a.zero = ctx->zero_page;
-  a.x_c16 = x_c16 ? 1 : 0; a.y_c16 = y_c16 ? 1 : 0;
+  a.x_c16 = x_c16 ? 1 : 0; a.y_c16 = y_c16 ? 1 : 0; a.res0_c16 = sc_c16 ? 1 : 0;
   const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
   for (int k = 0; k < 3; ++k) {
     a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
@@ -478,9 +479,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     if (s <= 0 || s >= m.n_stages || m.exact || no_chain) return false;
     const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
     const mlt::PackedConv &c2 = m.blocks[s][0].conv2;
-    // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave) is correct and bit-identical but NOT faster
-    // as built: 1.50 ms against 3 x 0.39 ms (452 B of scratch per lane at the 256-VGPR cap, next-sample input DMA exposed) -- opt-in.
-    static const bool chain64 = std::getenv("MLT_CHAIN64") != nullptr;
+    // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
+    // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
+    static const bool chain64 = std::getenv("MLT_NO_CHAIN64") == nullptr;
     const bool packing_ok = m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3);  // what chain_kernel<C> streams
     return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
@@ -521,11 +522,15 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         hout = ho;
         if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if (chain_s2) hout = ho;
-      else if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      else {
+        // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
+        io.ysc_c16 = chain && m.planes[s] == 64 && !no_c16;
+        if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
+      }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
         if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
-                             cur_c16, out_c16, pool[2]))) return rc;
+                             cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
         cur = outs[s];
         cur_c16 = out_c16;
         h = hout;

@@ -24,6 +24,8 @@ struct ConvArgs {
   int y_c16;                   // 1: y is written chunk-major, [n][COUT/16][Hout*Hout][16] -- the layout the next stage's whole-stage
                                // kernel stages its 16-channel input patches from (contiguous 32-byte pixels instead of 32-byte pieces
                                // of 128/256-byte NHWC pixels: measured 2.2x HBM over-fetch on those)
+  int ysc_c16;                 // 1: y_sc chunk-major as well (its reader is the 64-channel chain's residual load: one cache line per
+                               // lane quad instead of four)
   float acc_scale;             // accumulators are multiplied by this before the bias (weights are stored * 2^s)
   // SC variant: second output = bn(conv1x1_stride2(x)) (projection shortcut, arch:44-50)
   void *y_sc;
@@ -82,8 +84,9 @@ struct ChainConv {
   int res_mode;        // 0 none, 1 from `res` (HBM, same layout as the output), 2 from the tile saved by an earlier conv
   int save;            // 1: keep this conv's activated output tile in registers as a later conv's residual
   const void *res;
-  void *y;             // non-final conv: also write the activated output to HBM (NHWC) -- the later residual when the chain does
-                       // not keep it in registers (64-channel stage: 128 accumulator registers leave no room)
+  void *y;             // non-final conv: also write the activated output to HBM (same bytes as NHWC, but in the writing wave's own
+                       // order: it is read back only by that wave) -- the later residual when the chain does not keep it in
+                       // registers (64-channel stage: 128 accumulator registers leave no room)
 };
 struct ChainArgs {
   const void *x;       // [n][H][H][C] fp16: input of the first conv; S2 variant: the STAGE input [n][2H][2H][C/2]
@@ -98,6 +101,7 @@ struct ChainArgs {
   void *y;             // [n][H][H][C] fp16 output of the last conv, or NULL (only the GAP sums are needed)
   int y_c16;           // y chunk-major (ConvArgs.y_c16)
   int x_c16;           // S2: the stage input x is chunk-major
+  int res0_c16;        // cv[0].res (the shortcut sc from HBM) is chunk-major (ConvArgs.ysc_c16)
   float *gap;          // fp32 GAP partial sums of the last conv's output [n][gap_slots][C], or NULL
   int gap_slots, gap_l;
   int n;

@@ -46,6 +46,7 @@
 // (debug builds only, scripts/phase_timing.py; perturbs the pipelining slightly)
 #ifdef MLT_PHASE_TIMING
 __device__ unsigned long long g_phase[16][8];
+__device__ unsigned long long g_phase_chain[4][16];  // chain_kernel: [C == 256][S2] x 16 phases (see scripts/phase_timing.py)
 extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
   if (reset) {
@@ -54,6 +55,20 @@ extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read(unsig
   }
   return 0;
 }
+extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read_chain(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_chain), sizeof(g_phase_chain)) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long z[4][16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_chain), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+// (one asm statement per stamp: s_memtime counts on lgkmcnt and returns out of order with LDS reads, so it must not be in flight
+// inside the sections with counted lgkmcnt waits)
+#define PHC_STAMP(t_) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory")
+#define PHC_DECL unsigned int phc_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long phc_t; PHC_STAMP(phc_t)
+#define PHC_MARK(i) do { unsigned long long n_; PHC_STAMP(n_); phc_acc[i] += (unsigned int)(n_ - phc_t); phc_t = n_; } while (0)
+#define PHC_FLUSH(id) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_chain[id][i_], (unsigned long long)phc_acc[i_]); } } while (0)
 #define PH_DECL unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter()
 #define PH_MARK(i) do { unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
 #define PH_FLUSH(id) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase[id][i_], ph_acc[i_]); } } while (0)
@@ -61,6 +76,9 @@ extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read(unsig
 #define PH_DECL
 #define PH_MARK(i)
 #define PH_FLUSH(id)
+#define PHC_DECL
+#define PHC_MARK(i)
+#define PHC_FLUSH(id)
 #endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -222,7 +240,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
         }
         if constexpr (SC) {
           const uint4v w = pair16(sq[2 * qq], sq[2 * qq + 1]);
-          if (ok) *(uint4v *)((_Float16 *)a.y_sc + o16 + 16 * qq) = w;
+          if (NSPLIT == 1 && a.ysc_c16) {  // chunk-major, as y above
+            const int op = ok ? opix[j] : 0, hw_l = 2 * a.hout_l, nn = op >> hw_l, pix = op & ((1 << hw_l) - 1);
+            const int chunk = (ctile * CT + (wc * WCB + i) * 32 + 16 * qq) >> 4;
+            if (ok) *(uint4v *)((_Float16 *)a.y_sc + ((((size_t)nn * (COUT / 16) + chunk) << hw_l) + pix) * 16 + 8 * h) = w;
+          } else if (ok) *(uint4v *)((_Float16 *)a.y_sc + o16 + 16 * qq) = w;
           if constexpr (NSPLIT == 2) {
             const uint4v wl = pair16(sl[2 * qq], sl[2 * qq + 1]);
             if (ok) *(uint4v *)((char *)((_Float16 *)a.y_sc + o16 + 16 * qq) + a.ysc_lo_off) = wl;
@@ -1278,6 +1300,16 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
 
 
 
+// A kernel argument re-read from the kernarg segment AT THE POINT OF USE (one s_load, base pointer made opaque): for pointers that are
+// needed once per tile in a kernel whose scalar registers are exhausted -- kept live they are spilled to a VGPR lane and from there to
+// scratch, and every scratch reload costs a round trip plus an s_waitcnt vmcnt(0) that drains the LDS-DMA in flight.
+template <class T> __device__ __forceinline__ T karg_reload(size_t off) {
+  const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return *(const __attribute__((address_space(4))) T *)(ka + off);
+}
+#define KARG(type, member) karg_reload<type>(offsetof(ChainArgs, member))
+
 // ---------------------------------------------------------------------------------------------
 // Fused chain of stride-1 3x3 convs on WHOLE samples (the BasicBlock tail of the 128@16 stage, arch:52-57):
 //     b0 = relu(bn2(conv2(t)) + sc) ;  t1 = relu(bn1(conv1(b0))) ;  out = relu(bn2(conv2(t1)) + b0)  (+ GAP, arch:288)
@@ -1433,23 +1465,45 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   // ---- S2: input patch of stride-2 step i (16 channels, chunk i % NCS) -> patch buffer (i + 1) & 1 (patch waves).  Patch pixel
   // qS = (sample * PRS + r) * PCW + k holds input pixel (r - 1, k <= H ? 2k - 1 : 2(k - H - 1)); its two 16-byte channel slots are
   // swapped when bit 3 of qS is set (16 consecutive patch pixels span two 256-byte bank rows).  Outside the picture: zero page.
-  auto patch_dma = [&](int tile, int i) {  // every wave issues its share
-    const int chunk = i % NCS;
-    char *dst = smem + pbuf(i) * PBYTES;
+  // Addressing: everything that depends only on (lane, piece) is packed ONCE into 32 bits per piece -- byte offset inside the
+  // (sample, 16-channel chunk) | sample-in-tile << 30 | "outside the picture" << 31 -- and the 64-bit source address is formed at the
+  // point of issue from an opaque copy.  Left to itself the compiler precomputes the 64-bit addresses of all pieces at the top of a
+  // tile, runs out of registers, and reloads them from scratch BETWEEN the DMA instructions: every reload is followed by
+  // s_waitcnt vmcnt(0), i.e. by a full round trip of the piece just requested (seen in the ISA: 280 B of scratch, 3 serialised round
+  // trips per stride-2 step and 5 in front of the last epilogue's stores).
+  constexpr int PPW = (PPIECE + NW - 1) / NW;
+  uint32_t pvo[S2 ? PPW : 1];
+  if constexpr (S2) {
 #pragma unroll
-    for (int k = 0; k < (PPIECE + NW - 1) / NW; ++k) {
+    for (int k = 0; k < PPW; ++k) {
       const int piece = wave + k * NW;
-      if (piece >= PPIECE) break;  // wave-uniform
       const int it = piece * 64 + lane, qS = it >> 1, pos = it & 1;
       const int sl = pos ^ ((qS >> 3) & 1);
       const int sm = qS / PPS, rem = qS - sm * PPS, r = rem / PCW, kk = rem - r * PCW;
       const int ri = r - 1, ci = kk <= H ? 2 * kk - 1 : 2 * (kk - H - 1);
-      int n = (tile << SPW_L) + sm;
-      n = n < a.n ? n : a.n - 1;
       const bool live = qS < PPIX && ri >= 0 && ri < HIN && ci >= 0 && ci < HIN;
-      const size_t off = a.x_c16 ? ((((size_t)n * NCS + chunk) * HIN + ri) * HIN + ci) * KCS + sl * 8           // [n][CIN/16][HIN*HIN][16]
-                                 : (((size_t)n * HIN + ri) * HIN + ci) * CIN + chunk * KCS + sl * 8;           // NHWC
-      const char *src = live ? (const char *)a.x + off * 2 : (const char *)a.zero + ((((int)blockIdx.x * 64 * NW + tid) * 16) & 0xFFF0);
+      const uint32_t off = a.x_c16 ? ((ri * HIN + ci) * KCS + sl * 8) * 2   // [n][CIN/16][HIN*HIN][16]
+                                   : ((ri * HIN + ci) * CIN + sl * 8) * 2;  // NHWC
+      pvo[k] = live ? off | ((uint32_t)sm << 30) : 0x80000000u;
+    }
+  }
+  const uint32_t chunk_stride = a.x_c16 ? HIN * HIN * KCS * 2 : KCS * 2;
+  auto patch_dma = [&](int tile, int i) {  // every wave issues its share
+    const int chunk = i % NCS;
+    char *dst = smem + pbuf(i) * PBYTES;
+    const char *xb = (const char *)a.x + (size_t)chunk * chunk_stride;
+    uint32_t zo = ((int)blockIdx.x * 64 * NW + tid) * 16;
+    asm volatile("" : "+v"(zo));
+    const char *zsrc = (const char *)a.zero + (zo & 0xFFF0);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int piece = wave + k * NW;
+      if (piece >= PPIECE) break;  // wave-uniform
+      uint32_t v = pvo[k];
+      asm volatile("" : "+v"(v));
+      int n = (tile << SPW_L) + (int)((v >> 30) & 1);
+      n = n < a.n ? n : a.n - 1;
+      const char *src = (int)v < 0 ? zsrc : xb + (size_t)n * (size_t)(CIN * HIN * HIN * 2) + (v & 0x3FFFFFFFu);
       glds16(src, dst + piece * 1024);
     }
   };
@@ -1457,11 +1511,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   // pos ^ ((q >> 1) & 7) of that pixel ----
   auto dma_region = [&](int tile, int c) {
     if (!patch_wave) return;
+    // per-piece source offsets are formed here (a few bit operations) from a rematerialised lane id, not hoisted and kept live
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int k = 0; k < PPR; ++k) {
       const int piece = (wave - WP0) + k * NWP;
       if (piece >= RPIECE) break;  // wave-uniform
-      const int it = piece * 64 + lane, q = it / SLOTS, pos = it & (SLOTS - 1);
+      const int it = piece * 64 + ln, q = it / SLOTS, pos = it & (SLOTS - 1);
       const int sl = pos ^ swz(q);
       int n = (tile << SPW_L) + (q >> (2 * HL));
       n = n < a.n ? n : a.n - 1;  // ragged last tile: a valid sample again (its outputs are masked)
@@ -1483,6 +1540,35 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   int slot_rd = 0;
+  PHC_DECL;
+  // Biases live in registers for the life of the (persistent) workgroup: lane l holds the bias of cout (wc * WCB) * 32 + l of every
+  // conv and cout pass (5 VGPRs for the 128 stage, 10 for the 256 stage); an epilogue fetches the 16 values of its accumulator rows
+  // with ds_bpermute (crossbar only, no LDS memory).  A bias LOADED in an epilogue costs an exposed L2 round trip four times per
+  // tile, and the compiler's s_waitcnt vmcnt(0) in front of its first use also waits for whatever LDS-DMA was issued before it --
+  // in the last epilogue that is the next tile's complete input patch.
+  constexpr bool PBIAS = WCB == 2;
+  float pb_cv[NCONV][NPASS], pb_t[NPASS], pb_sc[NPASS];
+  if constexpr (PBIAS) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+      for (int c = 0; c < NCONV; ++c) pb_cv[c][ps] = a.cv[c].bias[ps * CT + (wc * WCB) * 32 + lane];
+      if constexpr (S2) {
+        pb_t[ps] = a.s2_bias[ps * CT + (wc * WCB) * 32 + lane];
+        pb_sc[ps] = a.s2_bias_sc[ps * CT + (wc * WCB) * 32 + lane];
+      }
+    }
+  }
+  const int pb_lane = 16 * h;  // byte address of lane 4 * h for ds_bpermute
+  auto bias_rows = [&](float v, int i, float4v(&out)[4]) {  // out[q][e] = bias of accumulator row 8 * q + 4 * h + e of cout block i
+    int base = pb_lane;
+    asm volatile("" : "+v"(v), "+v"(base));  // (or the 16 results / lane addresses, tile-invariant, are hoisted out of the tile loop and stay live)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        out[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(base + (i * 32 + 8 * q + e) * 4, __builtin_bit_cast(int, v)));
+  };
   uint4v keep[NPASS][WCB][WPB][2];  // residual tile saved by an earlier conv of the chain (packed fp16, pair16 layout)
   uint4v hold0[WCB][WPB][2];        // S2, two cout passes: pass 0's t tile while pass 1 still reads the input patches
 #pragma unroll
@@ -1494,28 +1580,62 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) keep[ps][i][j][qq] = uint4v{0u, 0u, 0u, 0u};
 
+  // L2 prefetch of the NEXT tile's input (whole-stage variant and the single-region 64-channel chain: the buffer the input will be
+  // DMA'd into is busy until the last step, so the request itself cannot be early).  All workgroups run in step, so every CU asks
+  // for its next 128 KiB within the same few microseconds at the end of a tile and then sits waiting (phase stamps: 11 % of the
+  // 64-channel chain at the tile top, 2-4 % per stride-2 step wait of the stages).  The patch waves -- which have no memory wait
+  // inside the last conv -- touch one dword of every 128-byte line of that input during the last conv's first step: the lines
+  // come to L2 / MALL with 10+ us to spare and the LDS-DMA that follows is an L2 hit.  The destination register is never read; it
+  // is kept live (one VGPR, same register for every load: checked in the ISA) up to the vmcnt(0) at the next tile's top.
+  constexpr bool L2PF = S2 || NCHUNK == 1;
+  constexpr int PF_BYTES = S2 ? (CIN * HIN * HIN * 2) << SPW_L : M * C * 2, PF_PER_LANE = PF_BYTES / 128 / (NWP * 64);
+  static_assert(!L2PF || (PF_BYTES % (128 * NWP * 64) == 0 && PF_PER_LANE >= 1 && PF_PER_LANE <= 8), "prefetch split");
+  uint32_t pf_reg = 0;
+  auto l2_prefetch_next = [&](int tile) {
+    if (!patch_wave || ((tile + 1) << SPW_L) > a.n) return;  // (a ragged last tile is not prefetched: the lines behind the buffer are not ours)
+    const char *base = (const char *)a.x + (size_t)tile * PF_BYTES + (size_t)((wave - WP0) * 64 + lane) * 128;
+#pragma unroll
+    for (int k = 0; k < PF_PER_LANE; ++k)
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_reg) : "v"(base + (size_t)k * (NWP * 64 * 128)) : "memory");
+  };
+
   for (; t < ntiles; t += tstep) {
     // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
 #pragma unroll
     for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(pj[j]));
     const bool has_next = t + tstep < ntiles;
     int opix[WPB], gidx[WPB];  // flattened (n, y, x) of this lane's output pixels, GAP partial-sum rows
+    auto out_index = [&]() {
 #pragma unroll
-    for (int j = 0; j < WPB; ++j) {
-      const int nn = (t << SPW_L) + (pj[j] >> (2 * HL));
-      const bool ok = nn < a.n;
-      opix[j] = ok ? nn * HW + (pj[j] & (HW - 1)) : -1;
-      gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
-    }
+      for (int j = 0; j < WPB; ++j) {
+        const int nn = (t << SPW_L) + (pj[j] >> (2 * HL));
+        const bool ok = nn < a.n;
+        opix[j] = ok ? nn * HW + (pj[j] & (HW - 1)) : -1;
+        gidx[j] = ok ? nn * a.gap_slots + ((mj[j] & (HW - 1)) >> 5) : -1;
+      }
+    };
+    // whole-stage variant: only the last epilogue needs them -- computed there from opaque copies, or the store addresses derived
+    // from them are formed up here and live (= spilled) across the whole tile
+    if constexpr (!S2 && KEEP) out_index();
+    auto out_index_late = [&]() {
+#pragma unroll
+      for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(pj[j]), "+v"(mj[j]));
+      out_index();
+    };
 
     if constexpr (!S2 && NCHUNK == 1) {  // single-region buffer: the next sample's input was requested only after the previous tile's last step
       if (patch_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PHC_MARK(1);
       asm volatile("s_barrier" ::: "memory");
+      asm volatile("" : "+v"(pf_reg));
+      PHC_MARK(0);
     }
     if constexpr (S2) {
       // ================= stride-2 conv + projection shortcut of the stage, on this tile =================
       // patches 0 and 1 and the first weight step of this tile (issued a tile ago / in the prologue; every wave has a share)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("" : "+v"(pf_reg));
+      PHC_MARK(0);
       int bS[WPB];  // patch pixel of tap (0, 0) for this lane's output pixels
 #pragma unroll
       for (int j = 0; j < WPB; ++j) bS[j] = ((pj[j] >> (2 * HL)) * PRS + 2 * ((pj[j] >> HL) & (H - 1))) * PCW + (pj[j] & (H - 1));
@@ -1573,7 +1693,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 }
             });
           }
+          PHC_MARK(1);
           asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next weight step (ring waves) and next patch (patch waves) landed
+          PHC_MARK(2);
           --ahead;
         }
         // t = relu(bn1(conv)) -> activation buffer (pass 0 of 2: held until pass 1 has read its patches -- they overlap the buffer);
@@ -1581,10 +1703,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
         for (int i = 0; i < WCB; ++i) {
           float4v b1[4], bs[4];
+          if constexpr (PBIAS) {
+            bias_rows(pb_t[ps], i, b1);
+            bias_rows(pb_sc[ps], i, bs);
+          } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            b1[q] = *(const float4v *)(a.s2_bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
-            bs[q] = *(const float4v *)(a.s2_bias_sc + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+            for (int q = 0; q < 4; ++q) {
+              b1[q] = *(const float4v *)(a.s2_bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+              bs[q] = *(const float4v *)(a.s2_bias_sc + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+            }
           }
 #pragma unroll
           for (int j = 0; j < WPB; ++j)
@@ -1614,6 +1741,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
         }
       });
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PHC_MARK(3);
     }
 
     static_for<NCONV>([&](auto kc) {
@@ -1646,6 +1774,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll 1
           for (int g = 0; g < NG; ++g) {
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
+            if constexpr (L2PF && lastc && ps == 0) {
+              if (chunk == 0 && g == 0 && has_next) l2_prefetch_next(t + tstep);
+            }
             // the last K loop has finished reading region chunk-1: the next sample's input may land there
             if (!S2 && last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
             if (RES == 1 && !RES_LATE && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
@@ -1726,18 +1857,31 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
                   for (int qq = 0; qq < 2; ++qq) asm volatile("" : "=v"(resv[i][j][qq]));
               if (chunk == NCHUNK - 1 && g == NG - 1) {
+                out_index_late();
+                const _Float16 *resb = (const _Float16 *)KARG(const void *, cv[cvi].res);
+                const bool res0_c16 = cvi == 0 && KARG(int, res0_c16) != 0;
 #pragma unroll
                 for (int i = 0; i < WCB; ++i)
 #pragma unroll
                   for (int j = 0; j < WPB; ++j) {
-                    const size_t o = (size_t)(opix[j] >= 0 ? opix[j] : 0) * C + ps * CT + (wc * WCB + i) * 32 + 8 * h;
+                    // cvi == 0: sc, written NHWC by the stride-2 kernel; else b0, written by this wave below in its own order
+                    // (lane-linear 1 KiB blocks: a quad of lanes touches ONE 64-byte span instead of four cache lines)
+                    const int op0 = opix[j] >= 0 ? opix[j] : 0;
+                    const size_t o = cvi != 0       ? (((size_t)t * NW + wave) * (WCB * WPB * 2) + (i * WPB + j) * 2) * 512 + lane * 8
+                                     : res0_c16 ? ((((size_t)(op0 >> (2 * HL)) * (C / 16) + ((ps * CT + (wc * WCB + i) * 32) >> 4)) << (2 * HL)) + (op0 & (HW - 1))) * 16 + 8 * h
+                                                : (size_t)op0 * C + ps * CT + (wc * WCB + i) * 32 + 8 * h;
+                    // (asm loads: the compiler does not track them, so the epilogue's first use is not preceded by its
+                    // s_waitcnt vmcnt(0) -- which would also drain the next sample's input DMA issued in between; the wait is below)
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = *(const uint4v *)((const _Float16 *)cv.res + o + 16 * qq);
+                    for (int qq = 0; qq < 2; ++qq) {
+                      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(resv[i][j][qq]) : "v"(resb + o + (cvi != 0 ? 512 : res0_c16 ? HW * 16 : 16) * qq) : "memory");
+                    }
                   }
               }
             }
             // ---- end of step: next ring step landed (ring waves); next sample's regions landed (patch waves) where the
             // following step reads them ----
+            PHC_MARK(4 + 3 * cvi);
             if constexpr (SPLIT_ROLES) {
               if (ring_wave) {  // the step after this one has landed; the ahead - 2 younger ones may still fly
                 if (PFD >= 3 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPWR) : "memory");
@@ -1751,9 +1895,13 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             } else {
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if constexpr (RES == 1 && RES_LATE) {  // the residual tile requested above (every wave)
+              if (chunk == NCHUNK - 1 && g == NG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
 #ifndef KO_CH_BARRIER
             asm volatile("s_barrier" ::: "memory");
 #endif
+            PHC_MARK(5 + 3 * cvi);
             --ahead;
             if (++slot_rd == NBUF) slot_rd = 0;
           }
@@ -1768,11 +1916,17 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
               }
             } else if (has_next) dma_region(t + tstep, NCHUNK - 1);
           }
+          if constexpr (S2 || !KEEP) out_index_late();
+          auto std_epi = [&]() {
           float4v bq[WCB][4], bsq[1][4];
 #pragma unroll
-          for (int i = 0; i < WCB; ++i)
+          for (int i = 0; i < WCB; ++i) {
+            if constexpr (PBIAS) bias_rows(pb_cv[cvi][ps], i, bq[i]);
+            else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+              for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+            }
+          }
           ConvArgs ea{};
           ea.y = a.y; ea.gap = a.gap; ea.gap_slots = a.gap_slots; ea.gap_l = a.gap_l; ea.acc_scale = cv.acc_scale; ea.relu = 1;
           ea.y_c16 = a.y_c16; ea.hout_l = HL;
@@ -1787,9 +1941,39 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) resv[i][j][qq] = keep[ps][i][j][qq];
           }
-          conv_epilogue<C, CT, WCB, WPB, false, 1>(ea, ps, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+          int he = h, pe = p;
+          asm volatile("" : "+v"(he), "+v"(pe));  // nothing of the epilogue's lane arithmetic is hoisted out of the tile loop
+          conv_epilogue<C, CT, WCB, WPB, false, 1>(ea, ps, wc, he, pe, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+          };
+          // !KEEP (8 accumulators + the residual tile in registers): the same epilogue one 32-cout block at a time, so that only one
+          // block's 16 bias values are live (both blocks' at once, as above, spilled)
+          auto blk_epi = [&]() {
+            ConvArgs ea{};
+            ea.y = KARG(void *, y); ea.gap = KARG(float *, gap); ea.gap_slots = KARG(int, gap_slots); ea.gap_l = KARG(int, gap_l);
+            ea.acc_scale = KARG(float, cv[cvi].acc_scale); ea.relu = 1;
+            ea.y_c16 = KARG(int, y_c16); ea.hout_l = HL;
+            ea.res = RES ? (const void *)ea.y : nullptr;  // (only its non-NULLness is looked at)
+            float16v acc_sc[1][1];
+            uint4v resl[1][1][2];
+            float4v bsq[1][4];
+#pragma unroll
+            for (int i = 0; i < WCB; ++i) {
+              float4v bq1[1][4];
+              bias_rows(pb_cv[cvi][ps], i, bq1[0]);
+              if (i) out_index_late();  // (recomputed per block: two 64-bit GAP row offsets kept across block 0 were spilled)
+              int he = h, pe = p;
+              asm volatile("" : "+v"(he), "+v"(pe));
+              conv_epilogue<C, CT, 1, WPB, false, 1>(ea, ps, wc * WCB + i, he, pe, opix, gidx, reinterpret_cast<float16v(&)[1][WPB]>(acc[i]), acc_sc, bq1, bsq,
+                                                     reinterpret_cast<const uint4v(&)[1][WPB][2]>(resv[i]), resl);
+            }
+          };
+          if constexpr (!KEEP && PBIAS) blk_epi();
+          else std_epi();
+          PHC_MARK(6 + 3 * cvi);
         } else {
           // + bias (+ residual) (ReLU) -> fp16 -> back into the activation buffer (input of the next conv)
+          _Float16 *yb0 = nullptr;  // !KEEP: HBM copy of this conv's output (the later residual), private layout (see the loads)
+          if constexpr (!KEEP) yb0 = (_Float16 *)KARG(void *, cv[cvi].y);
           auto put = [&](int pass, int i, int j, int qq, uint4v w) {  // this lane: channels cb .. cb+7 of pixel pj[j]
             const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
             *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = w;
@@ -1797,8 +1981,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
           for (int i = 0; i < WCB; ++i) {
             float4v bi[4];
+            if constexpr (PBIAS) bias_rows(pb_cv[cvi][ps], i, bi);
+            else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bi[q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+              for (int q = 0; q < 4; ++q) bi[q] = *(const float4v *)(cv.bias + ps * CT + (wc * WCB + i) * 32 + 4 * h + 8 * q);
+            }
 #pragma unroll
             for (int j = 0; j < WPB; ++j)
 #pragma unroll
@@ -1816,7 +2003,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 const uint4v w = pair16(hq[0], hq[1]);
                 if constexpr (SAVE) keep[ps][i][j][qq] = w;
                 if constexpr (!KEEP) {  // the later residual goes through HBM
-                  if (cv.y && opix[j] >= 0) *(uint4v *)((_Float16 *)cv.y + (size_t)opix[j] * C + ps * CT + (wc * WCB + i) * 32 + 8 * h + 16 * qq) = w;
+                  if (yb0) *(uint4v *)(yb0 + (((size_t)t * NW + wave) * (WCB * WPB * 2) + (i * WPB + j) * 2 + qq) * 512 + lane * 8) = w;
                 }
                 if constexpr (ps == NPASS - 1) put(ps, i, j, qq, w);
                 else hold[i][j][qq] = w;
@@ -1833,10 +2020,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           }
+          PHC_MARK(6 + 3 * cvi);
         }
       });
     });
   }
+  PHC_FLUSH((C == 256 ? 2 : 0) + (S2 ? 1 : 0));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -14,8 +14,8 @@ os.environ["MLT_LIB_PATH"] = out
 import torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-blob = pkg.weights.synthetic_blob(0, 1)
-m = pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob}, max_batch=n)
+blob = pkg.weights.synthetic_blob(0, 10)
+m = pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob}, max_batch=n, flags=pkg.capi.FLAG_NO_CALIBRATION)
 org, pred = pkg.synth.make_patches_bulk(128, n, 3)
 poc, qp = pkg.synth.make_scalars(n, 3)
 dev = torch.device("cuda:0")
@@ -41,3 +41,17 @@ for kid in range(16):
     print(f"kernel id {kid} (cin={32 * (kid & 7)}, stride={2 if kid & 8 else 1}): total {tot / 1e6:.1f} Mcycles (wave 0, all WGs, all launches)")
     for nm, v in zip(names, row):
         print(f"   {nm:40s} {100.0 * v / tot:5.1f} %")
+
+cbuf = (C.c_ulonglong * 64)()
+lib.mlt_debug_phase_read_chain(cbuf, 0)
+cnames = ["tile top: wait for patches 0/1 + first weight step (64 chain: barrier after own vmcnt wait)", "S2 steps: reads + MFMA (64 chain: own wait for the input DMA at the tile top)", "S2 steps: end wait + barrier", "S2 epilogue (bias, t -> LDS, sc -> regs, barrier)",
+          "conv 0 steps: reads + MFMA", "conv 0 steps: end wait + barrier", "conv 0 epilogue", "conv 1 steps: reads + MFMA", "conv 1 steps: end wait + barrier",
+          "conv 1 epilogue", "conv 2 steps: reads + MFMA", "conv 2 steps: end wait + barrier", "conv 2 epilogue (HBM / GAP) + next tile's patch DMA issue"]
+for cid, nm in enumerate(["chain 128@16 or 64@32 (MLT_CHAIN64=1)", "stage 128@16 (S2)", "chain 256@8", "stage 256@8 (S2)"]):
+    row = [cbuf[cid * 16 + i] for i in range(16)]
+    tot = sum(row)
+    if not tot:
+        continue
+    print(f"chain_kernel {nm}: total {tot / 1e6:.1f} Mcycles (wave 0 of every workgroup, the last launch loop)")
+    for k, v in zip(cnames, row):
+        print(f"   {k:70s} {100.0 * v / tot:5.1f} %   {v / 1e6:9.2f} Mcyc")
