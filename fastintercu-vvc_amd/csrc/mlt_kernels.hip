@@ -1587,7 +1587,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   // inside the last conv -- touch one dword of every 128-byte line of that input during the last conv's first step: the lines
   // come to L2 / MALL with 10+ us to spare and the LDS-DMA that follows is an L2 hit.  The destination register is never read; it
   // is kept live (one VGPR, same register for every load: checked in the ISA) up to the vmcnt(0) at the next tile's top.
-  constexpr bool L2PF = S2 || NCHUNK == 1;
+#ifndef CFG_CHAIN_L2PF  // measured: no change (64 chain 1.242 -> 1.237 ms, stage step waits 3.3 -> 3.1 %): the waits are not HBM latency.  Off.
+#define CFG_CHAIN_L2PF 0
+#endif
+  constexpr bool L2PF = CFG_CHAIN_L2PF && (S2 || NCHUNK == 1);
   constexpr int PF_BYTES = S2 ? (CIN * HIN * HIN * 2) << SPW_L : M * C * 2, PF_PER_LANE = PF_BYTES / 128 / (NWP * 64);
   static_assert(!L2PF || (PF_BYTES % (128 * NWP * 64) == 0 && PF_PER_LANE >= 1 && PF_PER_LANE <= 8), "prefetch split");
   uint32_t pf_reg = 0;
@@ -1974,8 +1977,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
           // + bias (+ residual) (ReLU) -> fp16 -> back into the activation buffer (input of the next conv)
           _Float16 *yb0 = nullptr;  // !KEEP: HBM copy of this conv's output (the later residual), private layout (see the loads)
           if constexpr (!KEEP) yb0 = (_Float16 *)KARG(void *, cv[cvi].y);
+          // (lane half from a rematerialised lane id: h itself, kept live over the step loops, was spilled in the 64-channel chain and
+          // its reload's s_waitcnt vmcnt(0) drained the weight ring prefetch)
+          const int hm = KEEP ? h : (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 5;
           auto put = [&](int pass, int i, int j, int qq, uint4v w) {  // this lane: channels cb .. cb+7 of pixel pj[j]
-            const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * h;
+            const int cb = pass * CT + (wc * WCB + i) * 32 + 16 * qq + 8 * hm;
             *(uint4v *)(smem + (cb / KC) * REGION + pj[j] * (KC * 2) + ((((cb % KC) / 8) ^ swz(pj[j])) << 4)) = w;
           };
 #pragma unroll

@@ -13,13 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fastintercu-vvc_amd", "csrc", "mlt_kernels.hip")
 
 
-def main():
-    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-    want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else ""
+def collect(defs):
+    """{demangled kernel name: {glds, gload, scratch, waits: [(asm line, loop depth, text)]}} of mlt_kernels.hip built with defs"""
     out = "/tmp/isa_waits.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *defs, SRC, "-o", out],
                           stderr=subprocess.DEVNULL)
-    name, in_asm, depth, rows, stats = None, False, 0, [], {}
+    name, in_asm, depth, stats = None, False, 0, {}
     for ln, line in enumerate(open(out), 1):
         m = re.match(r"^(_Z\w+):", line)
         if m:
@@ -45,13 +44,19 @@ def main():
         t = line.strip()
         if t.startswith("global_load_lds"):
             st["glds"] += 1
-        elif t.startswith("global_load") or t.startswith("buffer_load"):
+        elif (t.startswith("global_load") or t.startswith("buffer_load")) and not in_asm:
             st["gload"] += 1
         elif t.startswith("scratch_"):
             st["scratch"] += 1
         elif t.startswith("s_waitcnt") and "vmcnt" in t and not in_asm:
             st["waits"].append((ln, depth, t))
-    for k, st in stats.items():
+    return stats
+
+
+def main():
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else ""
+    for k, st in collect(defs).items():
         if want not in k:
             continue
         inner = [w for w in st["waits"] if w[1] >= 1]

@@ -1,0 +1,49 @@
+"""ISA-level invariants of the whole-stage / chain kernels (hipcc cross-compiles gfx950 here, no GPU needed).
+
+What these guard ("compiler-made drains"): a scratch reload or a plain load whose first use sits inside a tile / step
+loop is preceded by the compiler's s_waitcnt vmcnt(0), which also drains every LDS-DMA piece in flight -- a serialised HBM round
+trip per occurrence.  Round 2 removed them from the three default chain kernels; this keeps them out."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
+STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
+CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 4, 1, 2, 3, true, false, false>"
+
+
+@pytest.fixture(scope="module")
+def stats():
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    import isa_waits
+    return isa_waits.collect([])
+
+
+def _find(stats, prefix):
+    hits = [v for k, v in stats.items() if k.startswith(prefix)]
+    assert len(hits) == 1, f"{prefix}: {len(hits)} instantiations"
+    return hits[0]
+
+
+@pytest.mark.parametrize("kernel", [STAGE_128, STAGE_256])
+def test_whole_stage_kernels_have_no_scratch_and_no_compiler_drain_in_loops(stats, kernel):
+    st = _find(stats, kernel)
+    assert st["scratch"] == 0, f"{kernel}: {st['scratch']} scratch ops (register spills)"
+    inner = [w for w in st["waits"] if w[1] >= 1]
+    assert not inner, f"{kernel}: compiler-generated vmcnt waits inside loops: {inner[:5]}"
+    assert st["glds"] > 50  # the LDS-DMA staging is there (guards against matching a different kernel)
+
+
+def test_64_channel_chain_spills_stay_out_of_the_step_loops(stats):
+    st = _find(stats, CHAIN_64)
+    assert st["scratch"] <= 8, f"{st['scratch']} scratch ops (round 2: 4, all at the tile end)"
+    deep = [w for w in st["waits"] if w[1] >= 2]
+    assert not deep, f"compiler-generated vmcnt waits inside the step loops: {deep[:5]}"
+    assert len([w for w in st["waits"] if w[1] >= 1]) <= 4
