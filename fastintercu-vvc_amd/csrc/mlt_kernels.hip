@@ -1346,10 +1346,11 @@ template <class T> __device__ __forceinline__ T karg_reload(size_t off) {
 //     MFMA loop.  One channel chunk only, so the next sample's input can be fetched only after the last step of the last conv.
 template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false, bool KEEP = true>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
-  constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = TAPS / GT;
+  constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = (TAPS + GT - 1) / GT, GT_LAST = TAPS - (NG - 1) * GT;  // a last, shorter tap group when GT does not divide 9
   constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NPASS = C / CT, NW = WAVES_C * WAVES_P;
   constexpr int H = 1 << HL, HW = H * H, M = HW << SPW_L;
-  static_assert(C % CT == 0 && NPASS <= 2 && M == 32 * WAVES_P * WPB && TAPS % GT == 0 && HW >= 32 && C % KC == 0, "tiling");
+  static_assert(C % CT == 0 && NPASS <= 2 && M == 32 * WAVES_P * WPB && HW >= 32 && C % KC == 0, "tiling");
+  static_assert(GT_LAST == GT || RB == 2, "a shorter last tap group issues fewer ring pieces: only with the uncounted vmcnt(0) wait of a 2-deep ring");
   constexpr int WCHUNK = GT * KS * CBT * 1024, NPIECE = WCHUNK / 1024, NBUF = RB, PFD = RB - 1;
   // SPLIT_ROLES: first half of the waves issues the ring DMA (and waits for it every step), second half the activation DMA;
   // otherwise every wave issues its share of both and waits for everything it issued at the end of a step
@@ -1402,6 +1403,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       pj[j] = ((q & ~7) | ((k & 1) << 2) | (k >> 1)) * 8 + (mj[j] & 7);
     } else pj[j] = mj[j];
   }
+  // maps wider than 8: a lane's pixel blocks are 32 pixels apart and position == pixel, so ONE register carries all of them (the
+  // opaque copies that keep address terms from being hoisted would otherwise pin 2 * WPB registers: the 64-channel chain is at the cap)
+  auto opaque_pixels = [&]() {
+    if constexpr (HL != 3 && WPB > 1) {
+#pragma unroll
+      for (int j = 1; j < WPB; ++j) { pj[j] = pj[0] + 32 * j; mj[j] = pj[j]; }
+      mj[0] = pj[0];
+    }
+  };
   // 16-byte channel slot swizzle of pixel q: two pixels share a 256-byte bank row; on 8-wide maps bit 5 of q (row a vs
   // a + 4) is folded in so that the two rows of a lane group use disjoint columns
   // (16-wide maps: bit 4 of q -- the row parity -- is folded in as well, so that the epilogue's ds_write_b128, whose 8-lane groups
@@ -1437,10 +1447,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
         const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
         const char *src = wsrc + (size_t)((r_ps * NCHUNK + r_ci) * TAPS + r_gi * GT) * (KS * CBT * 1024);
         char *dst = ring + slot_wr * WCHUNK;
+        const int npiece = (GT_LAST != GT && r_gi == NG - 1) ? GT_LAST * KS * CBT : NPIECE;  // (never read behind the layer's last tap)
 #pragma unroll
         for (int k = 0; k < PPWR; ++k) {
           int pi = wave + k * NWR;
-          pi = pi < NPIECE ? pi : NPIECE - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
+          pi = pi < npiece ? pi : npiece - 1;  // every ring wave issues exactly PPWR instructions per step (counted vmcnt)
           glds16(src + pi * 1024 + lane16, dst + pi * 1024);
         }
       }
@@ -1606,6 +1617,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
 #pragma unroll
     for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(pj[j]));
+    opaque_pixels();
     const bool has_next = t + tstep < ntiles;
     int opix[WPB], gidx[WPB];  // flattened (n, y, x) of this lane's output pixels, GAP partial-sum rows
     auto out_index = [&]() {
@@ -1623,6 +1635,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
     auto out_index_late = [&]() {
 #pragma unroll
       for (int j = 0; j < WPB; ++j) asm volatile("" : "+v"(pj[j]), "+v"(mj[j]));
+      opaque_pixels();
       out_index();
     };
 
@@ -1774,8 +1787,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll 1
         for (int chunk = 0; chunk < NCHUNK; ++chunk) {
           const uint32_t pl = lds0 + chunk * REGION;
-#pragma unroll 1
-          for (int g = 0; g < NG; ++g) {
+          auto do_step = [&](int g, auto nitem_c) {
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
             if constexpr (L2PF && lastc && ps == 0) {
               if (chunk == 0 && g == 0 && has_next) l2_prefetch_next(t + tstep);
@@ -1793,7 +1805,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 }
             }
             {
-              constexpr int NITEM = GT * KS, NR = WCB + WPB;
+              constexpr int NITEM = decltype(nitem_c)::value, NR = WCB + WPB;
               const uint32_t wb = lds0 + ACT + slot_rd * WCHUNK + (wc * WCB) * 1024 + lane16;
               half8 fa[FD + 1][WCB], fb[FD + 1][WPB];
               uint32_t rowa[WPB], hs[WPB], mcur[WPB], mvs[FD + 1][WPB];
@@ -1907,7 +1919,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             PHC_MARK(5 + 3 * cvi);
             --ahead;
             if (++slot_rd == NBUF) slot_rd = 0;
-          }
+          };
+          // (a shorter last tap group is peeled: both item counts inside one loop body, selected by a branch, cost 900 B of scratch)
+#pragma unroll 1
+          for (int g = 0; g < (GT_LAST != GT ? NG - 1 : NG); ++g) do_step(g, std::integral_constant<int, GT * KS>{});
+          if constexpr (GT_LAST != GT) do_step(NG - 1, std::integral_constant<int, GT_LAST * KS>{});
         }
         // every wave is past the last step's barrier
         if constexpr (lastc) {
@@ -3076,6 +3092,9 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
 bool mlt_chain_supported(int c, int h) { return (c == 64 && h == 32) || (c == 128 && h == 16) || (c == 256 && h == 8); }
 bool mlt_stage_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }  // whole-stage (S2) variant
 
+#ifndef CFG_CHAIN64_GT   // taps per weight step of the 64-channel chain: 1 (4-deep ring of 8 KiB steps, 9 barriers per conv) or 2 (2 x 16 KiB, 5 barriers)
+#define CFG_CHAIN64_GT 2
+#endif
 #ifndef CFG_CHAIN_FD     // fragment prefetch distance of chain_kernel (items)
 #define CFG_CHAIN_FD 2
 #endif
@@ -3094,7 +3113,7 @@ hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int 
   if (c == 64 && h == 32 && a.nconv == 3 && !with_s2) {  // 8 waves x (64 couts x 128 pixels), one 128 KiB sample per workgroup, 4 x 8 KiB weight ring
     static_assert(CFG_64_WCB == 2 && CFG_64_WC == 1 && CFG_64_GT == 9, "chain_kernel<64,...> reads the packing of the stand-alone 64->64 layer");
     static DeviceOnce once64;
-    return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 4, 1, 2, 3, true, false, false>, once64, a, grid_x, 512, 128 * 1024 + 4 * 8 * 1024, st);
+    return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, CFG_CHAIN64_GT, CFG_CHAIN64_GT == 1 ? 4 : 2, 1, 2, 3, true, false, false>, once64, a, grid_x, 512, 128 * 1024 + 4 * 8 * 1024, st);
   }
   if (c == 128 && h == 16) {  // 8 waves x (64 couts x 64 pixels), one sample per workgroup
     if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[4], a, grid_x, 512, lds, st);
