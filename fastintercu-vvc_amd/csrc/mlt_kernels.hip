@@ -1419,7 +1419,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #ifndef CFG_CHAIN_SWZ16
 #define CFG_CHAIN_SWZ16 1
 #endif
-  auto swz = [](int q) { return ((q >> 1) & (SLOTS - 1)) ^ (HL == 3 ? ((q >> 5) & 1) << 2 : CFG_CHAIN_SWZ16 ? ((q >> 4) & 1) << 1 : 0); };
+#ifndef CFG_CHAIN_SWZ32  // 32-wide maps: 0 = no extra bit.  A read window of a dx = +-1 tap crosses a 16-pixel boundary there, and any
+#define CFG_CHAIN_SWZ32 0  // term that depends on bit 4 of q then maps two same-parity pixels of the window to one slot (2-way conflict on 6 of 9 taps)
+#endif
+  auto swz = [](int q) {
+    return ((q >> 1) & (SLOTS - 1)) ^ (HL == 3 ? ((q >> 5) & 1) << 2 : HL == 4 ? (CFG_CHAIN_SWZ16 ? ((q >> 4) & 1) << 1 : 0) : (CFG_CHAIN_SWZ32 ? ((q >> 4) & 1) << 1 : 0));
+  };
 
   const int ntiles = (a.n + (1 << SPW_L) - 1) >> SPW_L;
   int t = blockIdx.x;
