@@ -167,6 +167,31 @@ __device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // i
   ((uint32_t *)&qb)[0] = r0[1]; ((uint32_t *)&qb)[1] = r1[1];
 }
 
+// Four accumulators -> four activated fp16 values, in packed arithmetic: v_pk_fma_f32 (acc * scale + bias), v_pk_add_f32 (+ residual),
+// v_cvt_pk_f16_f32, v_pk_max_f16 -- 6 VALU ops per 4 values instead of 14 (the epilogues are VALU-bound phases in which no MFMA runs).
+// The ReLU is applied AFTER the rounding: max(0, .) commutes with a monotonic rounding, so the values are those of fmaxf before it.
+// x4 (optional) receives the fp32 values before the ReLU (GAP sums).
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int Q> __device__ __forceinline__ half4 act_quad(const float16v &A, float scale, const float4v &b, bool has_res, const half4 &r, bool relu, float *x4 = nullptr) {
+  half4 out;
+#pragma unroll
+  for (int ep = 0; ep < 2; ++ep) {
+    float2v a2 = {A[4 * Q + 2 * ep], A[4 * Q + 2 * ep + 1]};
+    const float2v b2 = {b[2 * ep], b[2 * ep + 1]};
+    float2v x2 = a2 * scale + b2;
+    if (has_res) {
+      const float2v r2 = {(float)r[2 * ep], (float)r[2 * ep + 1]};
+      x2 += r2;
+    }
+    if (x4) { x4[2 * ep] = x2[0]; x4[2 * ep + 1] = x2[1]; }
+    half2v h2 = __builtin_convertvector(x2, half2v);
+    if (relu) h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
+    out[2 * ep] = h2[0];
+    out[2 * ep + 1] = h2[1];
+  }
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue of the conv kernels: + bias (+ residual) (ReLU) -> fp16 NHWC (16 B per lane and quad pair) and/or
 // fp32 GAP partial sums; SC: second output (projection shortcut, no ReLU).  The caller has loaded the biases (bq / bsq)
@@ -204,6 +229,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
           unpair16(resv[i][j][qq], ra, rb);
           if constexpr (NSPLIT == 2) unpair16(resl[i][j][qq], rla, rlb);
         }
+        if constexpr (NSPLIT == 1) {
+          static_for<2>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            static_for<2>([&](auto qc) {
+              constexpr int qq_c = decltype(qc)::value;
+              if (qq_c == qq) {
+                constexpr int q = 2 * qq_c + k;
+                hq[q] = act_quad<q>(acc[i][j], a.acc_scale, bi[q], a.res != nullptr, k ? rb : ra, a.relu != 0, &v[4 * q]);
+                if constexpr (SC) {
+                  const half4 none{};
+                  sq[q] = act_quad<q>(acc_sc[i][j], a.acc_scale, bsi[q], false, none, false);
+                }
+              }
+            });
+          });
+        } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int q = 2 * qq + k;
@@ -224,6 +265,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
               sl[q][e] = (_Float16)(vs - (float)sq[q][e]);
             }
           }
+        }
         }
         // every lane takes part in the swaps; only valid pixels store
         if (a.y) {
@@ -255,6 +297,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, int ctile, int 
         // Sum over the pixels of one sample inside this 32-pixel block, in fp32, BEFORE any fp16 rounding.
         // Halving butterfly: after the steps for lane bits 0..3 each lane holds ONE channel's sum, channel
         // register index = b0*8 + b1*4 + b2*2 + b3 (b_k = bit k of p).  Fixed order => deterministic.
+        if constexpr (NSPLIT == 1) {  // (the packed path left the values of before the ReLU in v)
+          if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+        }
         if (!ok) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = 0.f;
@@ -1618,6 +1666,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       asm volatile("global_load_dword %0, %1, off" : "+v"(pf_reg) : "v"(base + (size_t)k * (NWP * 64 * 128)) : "memory");
   };
 
+#ifndef CFG_CHAIN_SCPF  // 64-channel chain: the patch waves pull THIS tile's sc (conv 0's residual, fresh from HBM) into L2 during conv 0's first step.
+#define CFG_CHAIN_SCPF 0  // Measured (3 x A/B on one box): launch 1.10 -> 1.11-1.13 ms, the 128 stage behind it 1.05 -> 1.09 ms.  Off.
+#endif
+  constexpr bool SCPF = CFG_CHAIN_SCPF && !KEEP && NCONV == 3 && !S2 && (M * C * 2) % (128 * NWP * 64) == 0;
+  auto l2_prefetch_sc = [&](int tile) {
+    if (!patch_wave) return;
+    const char *base = (const char *)KARG(const void *, cv[0].res) + (size_t)tile * (M * C * 2) + (size_t)((wave - WP0) * 64 + lane) * 128;
+#pragma unroll
+    for (int k = 0; k < (M * C * 2) / 128 / (NWP * 64); ++k)
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_reg) : "v"(base + (size_t)k * (NWP * 64 * 128)) : "memory");
+  };
+
   for (; t < ntiles; t += tstep) {
     // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
 #pragma unroll
@@ -1736,21 +1796,19 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
           }
 #pragma unroll
           for (int j = 0; j < WPB; ++j)
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
+            static_for<2>([&](auto qc) {
+              constexpr int qq = decltype(qc)::value;
               half4 ht[2], hc[2];
-#pragma unroll
-              for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  ht[kk][e] = (_Float16)fmaxf(acc[i][j][4 * (2 * qq + kk) + e] * a.s2_scale + b1[2 * qq + kk][e], 0.f);
-                  hc[kk][e] = (_Float16)(accs[i][j][4 * (2 * qq + kk) + e] * a.s2_scale + bs[2 * qq + kk][e]);
-                }
+              const half4 none{};
+              ht[0] = act_quad<2 * qq>(acc[i][j], a.s2_scale, b1[2 * qq], false, none, true);
+              ht[1] = act_quad<2 * qq + 1>(acc[i][j], a.s2_scale, b1[2 * qq + 1], false, none, true);
+              hc[0] = act_quad<2 * qq>(accs[i][j], a.s2_scale, bs[2 * qq], false, none, false);
+              hc[1] = act_quad<2 * qq + 1>(accs[i][j], a.s2_scale, bs[2 * qq + 1], false, none, false);
               keep[ps][i][j][qq] = pair16(hc[0], hc[1]);
               const uint4v wt = pair16(ht[0], ht[1]);
               if constexpr (NPASS == 2 && ps == 0) hold0[i][j][qq] = wt;  // pass 1 still reads the patches, which overlap the buffer
               else put_t(ps, i, j, qq, wt);
-            }
+            });
         }
         if constexpr (NPASS == 2 && ps == 1) {
 #pragma unroll
@@ -1796,6 +1854,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
             if constexpr (L2PF && lastc && ps == 0) {
               if (chunk == 0 && g == 0 && has_next) l2_prefetch_next(t + tstep);
+            }
+            if constexpr (SCPF && cvi == 0 && ps == 0) {
+              if (chunk == 0 && g == 0) l2_prefetch_sc(t);
             }
             // the last K loop has finished reading region chunk-1: the next sample's input may land there
             if (!S2 && last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
@@ -1916,7 +1977,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if constexpr (RES == 1 && RES_LATE) {  // the residual tile requested above (every wave)
-              if (chunk == NCHUNK - 1 && g == NG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (chunk == NCHUNK - 1 && g == NG - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(pf_reg));  // (the L2 prefetch loads have landed: their destination register is free from here)
+              }
             }
 #ifndef KO_CH_BARRIER
             asm volatile("s_barrier" ::: "memory");
@@ -2015,18 +2079,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             }
 #pragma unroll
             for (int j = 0; j < WPB; ++j)
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq) {
-                half4 ra, rb, hq[2];
+              static_for<2>([&](auto qc) {
+                constexpr int qq = decltype(qc)::value;
+                half4 ra{}, rb{}, hq[2];
                 if constexpr (RES != 0) unpair16(RES == 2 ? keep[ps][i][j][qq] : resv[i][j][qq], ra, rb);
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * (2 * qq + k) + e] * cv.acc_scale + bi[2 * qq + k][e];
-                    if constexpr (RES != 0) x += (float)(k ? rb[e] : ra[e]);
-                    hq[k][e] = (_Float16)fmaxf(x, 0.f);
-                  }
+                hq[0] = act_quad<2 * qq>(acc[i][j], cv.acc_scale, bi[2 * qq], RES != 0, ra, true);
+                hq[1] = act_quad<2 * qq + 1>(acc[i][j], cv.acc_scale, bi[2 * qq + 1], RES != 0, rb, true);
                 const uint4v w = pair16(hq[0], hq[1]);
                 if constexpr (SAVE) keep[ps][i][j][qq] = w;
                 if constexpr (!KEEP) {  // the later residual goes through HBM
@@ -2034,7 +2092,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 }
                 if constexpr (ps == NPASS - 1) put(ps, i, j, qq, w);
                 else hold[i][j][qq] = w;
-              }
+              });
           }
           if constexpr (ps == NPASS - 1) {
             if constexpr (NPASS == 2) {

@@ -351,9 +351,10 @@ def test_deferred_submit_flush_wait(gpu):
 
 def test_kernel_variant_switches_do_not_change_results(gpu):
     """Small launches use latency variants of the >= 64-channel convs (<= 16384 output pixels per launch: 64@32 up to 16 CUs,
-    128@16 / 64->128 up to 64, 256@8 / 128->256 up to 256); above that the 128- and 256-channel stages run as ONE whole-stage
-    launch each (chain_kernel S2: stride-2 conv + shortcut + three convs, intermediates in LDS / registers; 257 and 258 also
-    exercise its half-empty last tile of two samples).  A CU's logits must be bit-identical on either side of every switch
+    128@16 / 64->128 up to 64, 256@8 / 128->256 up to 256); above that the three stride-1 convs of the 64-channel stage run as
+    one chain launch (b0 through HBM in the writing wave's order, sc chunk-major) and the 128- and 256-channel stages as ONE
+    whole-stage launch each (chain_kernel S2: stride-2 conv + shortcut + three convs, intermediates in LDS / registers; 257 and
+    258 also exercise its half-empty last tile of two samples).  A CU's logits must be bit-identical on either side of every switch
     point, and equal to the oracle within the tolerance."""
     import oracle
     pkg = gpu

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
 STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
-CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 4, 1, 2, 3, true, false, false>"
+CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 2, 2, 1, 2, 3, true, false, false>"
 
 
 @pytest.fixture(scope="module")
