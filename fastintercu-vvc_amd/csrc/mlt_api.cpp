@@ -876,6 +876,21 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     return MLT_ERR_NOMEM;
   }
   ctx->own_stream = true;
+  if (mlt_chain_reads_beyond_lds()) {
+    // the chain kernels take conv padding from DS reads beyond the LDS allocation (zeros on gfx950): verify, once per context,
+    // that this device behaves so -- (ab)using the zero page as the 4-byte result slot, restored afterwards
+    int ok = 0;
+    const bool ran = mlt_probe_lds_oob((int *)ctx->zero_page, ctx->stream) == hipSuccess &&
+                     hipMemcpyAsync(&ok, ctx->zero_page, sizeof ok, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                     hipMemsetAsync(ctx->zero_page, 0, sizeof ok, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ran || !ok) {
+      g_init_error = ran ? "this device does not return zeros for LDS reads beyond the allocation (rebuild with -DCFG_CHAIN_OOBZERO=0)" : "LDS probe launch failed";
+      (void)hipFree(ctx->zero_page);
+      (void)hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return MLT_ERR_HIP;
+    }
+  }
   const uint32_t mask = cfg->size_mask ? cfg->size_mask : MLT_SIZE_128;  // reference gate: 128 only (EncCu.cpp:754)
   static const int sizes[4] = {128, 64, 32, 16};
   for (int i = 0; i < 4; ++i) {

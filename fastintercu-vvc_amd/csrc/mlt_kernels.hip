@@ -1467,6 +1467,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #ifndef CFG_CHAIN_SWZ16
 #define CFG_CHAIN_SWZ16 1
 #endif
+#ifndef CFG_CHAIN_OOBZERO  // 1: a tap outside the map reads an LDS address beyond the allocation (DS reads out of range return 0) instead of
+#define CFG_CHAIN_OOBZERO 1  //    the lane's own pixel ANDed with a zero mask (8 VALU ops per k-step and wave: knock-out -4..6 % per launch)
+#endif
 #ifndef CFG_CHAIN_SWZ32  // 32-wide maps: 0 = no extra bit.  A read window of a dx = +-1 tap crosses a 16-pixel boundary there, and any
 #define CFG_CHAIN_SWZ32 0  // term that depends on bit 4 of q then maps two same-parity pixels of the window to one slot (2-way conflict on 6 of 9 taps)
 #endif
@@ -1885,6 +1888,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                     const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;  // else: conv padding
                     const int q = ok ? pj[j] + (dy - 1) * H + (dx - 1) : pj[j];
                     rowa[j] = pl + q * (KC * 2);
+#if CFG_CHAIN_OOBZERO
+                    if (!ok) rowa[j] = 0x100000u;  // beyond the LDS: the read returns zeros, no mask needed
+#endif
                     hs[j] = (h * 16) ^ (swz(q) << 4);
                     mcur[j] = ok ? 0xFFFFFFFFu : 0u;
                   }
@@ -1918,7 +1924,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 for (int j = 0; j < WPB; ++j) {
                   lds_touch(fb[sl][j]);
                   bm[j] = fb[sl][j];
-#ifndef KO_CH_MASK
+#if !defined(KO_CH_MASK) && !CFG_CHAIN_OOBZERO
 #pragma unroll
                   for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
 #endif
@@ -3152,6 +3158,32 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int varian
 
 // fused chain kernels: (channels, map height) -> instantiation.  128@16: one sample per 16-wave workgroup, weights packed for
 // 128-cout tiles / 64-channel chunks / 3 taps per step (the stand-alone layer's packing).
+// ---- LDS out-of-range probe: chain_kernel (CFG_CHAIN_OOBZERO) lets a tap outside the map read beyond the LDS allocation and relies on
+// the hardware returning zeros for such a DS read.  One workgroup with the chain kernels' full 160 KiB allocation reads where they do;
+// *ok = 1 iff every lane saw zeros.  Run once per context at mlt_init: a device that answers differently is refused there. ----
+__global__ __launch_bounds__(64) void lds_oob_probe_kernel(int *ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  *(uint4v *)(smem + 160 * 1024 - 1024 + lane * 16) = uint4v{0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu};  // (the allocation is really there)
+  __syncthreads();
+  half8 v;
+  lds_read128<96>(v, 0x100000u + (uint32_t)lane * 16);  // same base as the chain kernels, an offset field in use
+  lds_wait<0>();
+  lds_touch(v);
+  const uint4v u = *(const uint4v *)&v;
+  const bool zero = (u[0] | u[1] | u[2] | u[3]) == 0;
+  const unsigned long long all = __ballot(zero);
+  if (lane == 0) *ok = all == ~0ull ? 1 : 0;
+}
+hipError_t mlt_probe_lds_oob(int *d_ok, hipStream_t st) {
+  static DeviceOnce once;
+  hipError_t e = ensure_big_lds(lds_oob_probe_kernel, once);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 160 * 1024, st, d_ok);
+  return hipGetLastError();
+}
+bool mlt_chain_reads_beyond_lds() { return CFG_CHAIN_OOBZERO != 0; }
+
 bool mlt_chain_supported(int c, int h) { return (c == 64 && h == 32) || (c == 128 && h == 16) || (c == 256 && h == 8); }
 bool mlt_stage_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }  // whole-stage (S2) variant
 

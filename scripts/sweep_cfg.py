@@ -11,10 +11,12 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "spread2": ["CFG_DMA_SPREAD=2"],
-    "spread3": ["CFG_DMA_SPREAD=3"],
-    "spread4": ["CFG_DMA_SPREAD=4"],
-    "base_b": [],
+    "ko_mask": ["KO_CH_MASK=1"],
+    "ko_ring": ["KO_CH_RING=1"],
+    "ko_barrier": ["KO_CH_BARRIER=1"],
+    "ko_reads": ["KO_CH_READS=1"],
+    "ko_ring_barrier": ["KO_CH_RING=1", "KO_CH_BARRIER=1"],
+    "ko_all": ["KO_CH_RING=1", "KO_CH_BARRIER=1", "KO_CH_MASK=1", "KO_CH_READS=1"],
 }
 
 
