@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   static_assert(RB >= 2 && RB <= 4, "ring depth");
   static_assert(SPLIT_ROLES || RB == 2, "unified issue waits with vmcnt(0)");
   static_assert(!S2 || KEEP, "the whole-stage variant keeps sc / b0 in registers");
-  static_assert(FD == 1 || FD == 2, "fragment prefetch distance");
+  static_assert(FD >= 1 && FD <= 3 && FD * (WCB + WPB) <= 15, "fragment prefetch distance");
   static_assert(((GT * KS - 1) * CBT + WCB - 1) * 1024 < 65536, "fragment offsets are ds_read immediates");
   // stride-2 front conv (S2)
   constexpr int CIN = C / 2, HIN = 2 * H, KCS = 16, NCS = CIN / KCS, TAPS_S = 10, NS = S2 ? NPASS * NCS : 0;
@@ -1912,6 +1912,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
               };
               issue(std::integral_constant<int, 0>{});
               if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
+              if constexpr (NITEM > 2 && FD > 2) issue(std::integral_constant<int, 2>{});
               static_for<NITEM>([&](auto ic) {
                 constexpr int item = decltype(ic)::value, sl = item % (FD + 1);
                 if constexpr (item + FD < NITEM) issue(std::integral_constant<int, item + FD>{});
