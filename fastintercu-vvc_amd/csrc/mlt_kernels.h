@@ -162,9 +162,9 @@ hipError_t mlt_launch_guard_scatter(const GuardScatterArgs &a, hipStream_t st);
 
 enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2, MLT_CONV_CENTRE = 3 };  // kernel variant of a layer shape
 bool mlt_conv_has_centre_variant(int cin, int cout);  // 1x1 (centre-tap) instantiation for stride-1 layers on 1x1 maps
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);
+hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);  // nsplit: 1 fast, 2 exact, 3 weights hi+lo only
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
-hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st);
+hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st);  // nsplit as mlt_launch_conv
 hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -416,7 +416,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   constexpr int NBUF = NG > 1 ? RB : 1;         // weight ring depth; steps are prefetched NBUF-1 ahead
   constexpr int PFD = NBUF > 1 ? NBUF - 1 : 0;  // prefetch distance (steps)
   constexpr int NPIECE = WCHUNK / 1024;                       // 1 KiB LDS-DMA pieces per step and plane
-  constexpr int PPW = NSPLIT * ((NPIECE + NW - 1) / NW);      // LDS-DMA instructions EVERY wave issues per step
+  // NSPLIT: 1 fast; 2 exact (weights AND activations are hi+lo pairs: Wh*Xh + Wh*Xl + Wl*Xh); 3 weights hi+lo only ((Wh + Wl) * X, 2 MFMAs,
+  // single activation planes): WS weight planes in the ring, XS activation planes in the patch / residual / outputs
+  constexpr int WS = NSPLIT >= 2 ? 2 : 1, XS = NSPLIT == 2 ? 2 : 1;
+  constexpr int PPW = WS * ((NPIECE + NW - 1) / NW);      // LDS-DMA instructions EVERY wave issues per step
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int SCW = SC ? WCB : 1, SPB = SC ? WPB : 1;
   static_assert(TT % GT == 0, "tap grouping");
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % WAVES_C, wp = wave / WAVES_C;
   char *patch = smem;                                                  // [NSPLIT][patch_bytes]; DMA: two buffers of patch_bytes
-  char *wring = smem + (DMA ? 2 : NSPLIT) * a.patch_bytes;             // [NBUF][NSPLIT][WCHUNK]
+  char *wring = smem + (DMA ? 2 : XS) * a.patch_bytes;                 // [NBUF][WS][WCHUNK]
   constexpr bool ASM_PIPE = CFG_ASM_PIPE && NSPLIT == 1;                // see lds_read128
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);            // LDS byte address of the dynamic segment
   constexpr int PIXROW_L = KC == 64 ? 1 : 2;                           // DMA swizzle: log2(pixels per 256-byte LDS bank row)
@@ -560,11 +563,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   const char *wsrc = (const char *)a.w + (size_t)(ctile / (CBK / CBT)) * NCHUNK * TT * (KS * CBK * 1024) + (size_t)(ctile % (CBK / CBT)) * CBT * 1024;
   auto issue_step = [&](int chunk, int g, int buf) {
     const char *src = wsrc + (size_t)(chunk * TT + g * GT) * (KS * CBK * 1024);
-    char *dst = wring + buf * NSPLIT * WCHUNK;
+    char *dst = wring + buf * WS * WCHUNK;
     // every wave issues exactly PPW instructions (the counted vmcnt below relies on it); a wave without a piece of
     // its own re-copies the last piece (same bytes to the same place: benign)
 #pragma unroll
-    for (int sp = 0; sp < NSPLIT; ++sp)
+    for (int sp = 0; sp < WS; ++sp)
 #pragma unroll
       for (int k = 0; k < (NPIECE + NW - 1) / NW; ++k) {
         int pi = wave + k * NW;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
   if constexpr (W_RESIDENT) issue_step(0, 0, 0);
 
   // residual prefetch registers (16 B per lane and quad pair, see pair16)
-  constexpr int NRES = WCB * WPB * 2 * NSPLIT;  // residual loads per lane
+  constexpr int NRES = WCB * WPB * 2 * XS;  // residual loads per lane
   uint4v resv[WCB][WPB][2], resl[NSPLIT == 2 ? WCB : 1][NSPLIT == 2 ? WPB : 1][2];
 
   // ---- DMA staging: UN LDS-DMA instructions per wave move one tile's patch; LDS position of item it is it * 16 bytes,
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       if (W_RESIDENT && chunk + 1 == NCHUNK) load_residual();
     };
     // loads in flight behind the ring's last counted wait of a chunk (prefetch_next): patch items (+ residual)
-    const int PF_PATCH = UN * NSPLIT;
+    const int PF_PATCH = UN * XS;
 
     bool all_ok = true;  // DMA: every lane of this wave stores (the counted wait at the end of the tile relies on it)
     if constexpr (DMA) {
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
       int cur_buf = 0;
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
-        char *wcur = wring + cur_buf * NSPLIT * WCHUNK;
+        char *wcur = wring + cur_buf * WS * WCHUNK;
         // last weight step of the tile: no ring wait follows it any more, so loads issued now fly under its MFMAs without
         // being drained by a counted vmcnt -- the residual arrives before the epilogue needs it
         if constexpr (RES_EARLY) {
@@ -905,14 +908,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
           });
         } else {
         static_assert(!KMAJ, "k-step-major items: asm-pipelined path only");
-        half8 af[2][WCB], bf[2][WPB], afl[2][NSPLIT == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
+        half8 af[2][WCB], bf[2][WPB], afl[2][WS == 2 ? WCB : 1], bfl[2][NSPLIT == 2 ? WPB : 1];
         auto load_frags = [&](int item, int sl) {
           const int tt = item / KS, ks = item - tt * KS;
           const int toff = tap_off(tt);
 #pragma unroll
           for (int i = 0; i < WCB; ++i) {
             af[sl][i] = *(const half8 *)(wcur + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
-            if constexpr (NSPLIT == 2) afl[sl][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
+            if constexpr (WS == 2) afl[sl][i] = *(const half8 *)(wcur + WCHUNK + ((tt * KS + ks) * CBT + wc * WCB + i) * 1024 + lane16);
           }
 #pragma unroll
           for (int j = 0; j < WPB; ++j) {
@@ -933,10 +936,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 #pragma unroll
                 for (int j = 0; j < WPB; ++j) {
                   acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
-                  if constexpr (NSPLIT == 2) {
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
-                    acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
-                  }
+                  if constexpr (NSPLIT == 2) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc_sc[i][j], 0, 0, 0);
+                  if constexpr (WS == 2) acc_sc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc_sc[i][j], 0, 0, 0);
                 }
             }
           } else {
@@ -945,10 +946,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
 #pragma unroll
               for (int j = 0; j < WPB; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                if constexpr (NSPLIT == 2) {
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                }
+                if constexpr (NSPLIT == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bfl[cur][j], acc[i][j], 0, 0, 0);
+                if constexpr (WS == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
               }
           }
         }
@@ -968,9 +967,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
               else if (infl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(1 * PPW) : "memory");
               else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             } else if (with_res) {  // infl == 0 here: every ring step has been issued before the prefetch
-              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT + NRES) : "memory");
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * XS + NRES) : "memory");
             } else {
-              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * NSPLIT) : "memory");
+              asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UN * XS) : "memory");
             }
             if (++cur_buf == NBUF) cur_buf = 0;
           }
@@ -999,7 +998,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void conv_mfma_kernel
         }
     }
   }
-  conv_epilogue<COUT, CT, WCB, WPB, SC, NSPLIT>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
+  conv_epilogue<COUT, CT, WCB, WPB, SC, XS>(a, ctile, wc, h, p, opix, gidx, acc, acc_sc, bq, bsq, resv, resl);
     // the next tile's commit overwrites the patch: every wave must be done reading it (and the GAP / stores above
     // do not touch LDS)
     PH_MARK(5);
@@ -2365,9 +2364,10 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
     }
   }
   // ---- A fragments (weights) stay in registers: 5 k-steps for t, 2 for sc, per split plane ----
-  half8 am[NSPLIT][5], as[NSPLIT][2];
+  constexpr int WS = NSPLIT >= 2 ? 2 : 1;  // weight planes (NSPLIT == 3: hi+lo weights, single outputs)
+  half8 am[WS][5], as[WS][2];
 #pragma unroll
-  for (int sp = 0; sp < NSPLIT; ++sp) {
+  for (int sp = 0; sp < WS; ++sp) {
     const char *w = (const char *)a.w + sp * a.w_lo_off;
 #pragma unroll
     for (int k = 0; k < 5; ++k) am[sp][k] = *(const half8 *)(w + k * 1024 + lane * 16);
@@ -2419,7 +2419,7 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
         else { const uint32_t v0 = slot_val(8 * ks + e), v1 = slot_val(8 * ks + 4 + e); bw[e] = h ? v1 : v0; }
       }
 #pragma unroll
-      for (int sp = 0; sp < NSPLIT; ++sp) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[sp][ks], b, acc, 0, 0, 0);
+      for (int sp = 0; sp < WS; ++sp) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[sp][ks], b, acc, 0, 0, 0);
     }
     // shortcut: 3x3 stride-2 taps (b_y, b_x) at raw offset tap(1 + b_y, 1 + b_x); slots 0..8 of 16
 #pragma unroll
@@ -2434,7 +2434,7 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
         bw[e] = h ? v1 : v0;
       }
 #pragma unroll
-      for (int sp = 0; sp < NSPLIT; ++sp) accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[sp][ks], b, accs, 0, 0, 0);
+      for (int sp = 0; sp < WS; ++sp) accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[sp][ks], b, accs, 0, 0, 0);
     }
     {
       const size_t ob = ok ? ((((size_t)(n0 + s) << hout_l) + gy) << hout_l) * 32 + (size_t)gx * 32 + 8 * h : 0;  // 16-byte span of quad pair 0
@@ -2882,8 +2882,8 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
-  const int patch_lds = (DMA ? 2 : NSPLIT) * a.patch_bytes;
-  const int lds = patch_lds + NBUF * NSPLIT * GT * (KC / 16) * CBT * 1024 + extra_lds;
+  const int patch_lds = (DMA ? 2 : (NSPLIT == 2 ? 2 : 1)) * a.patch_bytes;
+  const int lds = patch_lds + NBUF * (NSPLIT >= 2 ? 2 : 1) * GT * (KC / 16) * CBT * 1024 + extra_lds;
   static DeviceOnce once;
   if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -3096,6 +3096,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 #define CONV_CASE2(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WPF, WPE, GTF, GTE, RBF, RBE, UNF, UNE, MWF)                              \
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
     if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WPF, GTF, RBF, UNF, MWF, false>(a, grid_x, extra_lds, st); \
+    if (nsplit == 3) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 3, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st); \
     return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st);          \
   }
 #define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF) \
@@ -3104,8 +3105,11 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
 // stride-2 convs always carry their block's projection shortcut (layer0.0's lives in stem5_kernel).
 bool mlt_conv_has_centre_variant(int cin, int cout) { return (cin == cout && (cin == 128 || cin == 256)) || (cin == 128 && cout == 256); }
 
-hipError_t mlt_launch_conv(int cin, int cout, int stride, bool exact, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+// nsplit: 1 fast, 2 exact (weights and activations hi+lo), 3 weights hi+lo only (the tiling of the exact kernels, 2 MFMAs, single activation planes)
+hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+  const bool exact = nsplit >= 2;
   const bool dma = variant == MLT_CONV_DMA;
+  if (variant == MLT_CONV_CENTRE && nsplit == 3) return hipErrorInvalidValue;  // (1x1 maps: small-CU models only, which do not use this tier)
   if (variant == MLT_CONV_CENTRE) {  // stride-1 layers of the small-CU models on 1x1 maps: centre tap only (TAPS = 1), 128 samples per tile
     if (cin == 128 && cout == 128 && stride == 1)
       return exact ? launch_conv_t<128, 128, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
@@ -3228,8 +3232,9 @@ hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int 
   return hipErrorInvalidValue;
 }
 
-hipError_t mlt_launch_stem5(const Stem5Args &a, bool exact, int grid_x, int lds, hipStream_t st) {
-  if (exact) hipLaunchKernelGGL(stem5_kernel<2>, dim3(grid_x), dim3(256), lds, st, a);
+hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st) {
+  if (nsplit == 3) hipLaunchKernelGGL(stem5_kernel<3>, dim3(grid_x), dim3(256), lds, st, a);
+  else if (nsplit == 2) hipLaunchKernelGGL(stem5_kernel<2>, dim3(grid_x), dim3(256), lds, st, a);
   else hipLaunchKernelGGL(stem5_kernel<1>, dim3(grid_x), dim3(256), lds, st, a);
   return hipGetLastError();
 }

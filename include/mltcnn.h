@@ -87,15 +87,16 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out);
 /* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
  * blob arrives over RCCL broadcast instead of from weights_dir.  A size configured for the fast arithmetic is
  * CALIBRATED here: 48 seeded synthetic CUs run through the fast and the exact arithmetic on the device; the fast
- * arithmetic is kept only if 5.5 x rms|dlogit| <= tolerance and max|dlogit| <= 0.75 x tolerance, otherwise the size
- * runs exact (mlt_arithmetic reports the outcome). */
+ * arithmetic is kept only if 5.5 x rms|dlogit| <= tolerance and max|dlogit| <= 0.75 x tolerance; otherwise the 128 model
+ * tries a middle tier the same way -- fp16 (hi, lo) pairs for the WEIGHTS only, 2 MFMAs per product -- and a size that
+ * meets the contract with neither runs exact (mlt_arithmetic reports the outcome). */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 
 /* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
 typedef struct mlt_arith_info {
-  int32_t exact;          /* 1: (hi, lo) pairs, 0: fast */
+  int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations */
   int32_t calibrated;     /* 1: the calibration ran for this size */
-  float calib_rms, calib_max; /* |dlogit| fast vs exact over the calibration CUs */
+  float calib_rms, calib_max; /* |dlogit| of the chosen non-exact tier (or of the fast one if exact was chosen) vs exact over the calibration CUs */
   int32_t flat_guard, decision_guard;
   uint64_t guard_reruns;  /* CUs re-evaluated by the guards since init */
 } mlt_arith_info;

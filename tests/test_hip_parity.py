@@ -279,6 +279,43 @@ def test_load_time_calibration_picks_the_arithmetic(gpu):
         c.close()
 
 
+def test_middle_tier_hi_lo_weights(gpu):
+    """A weight set that fails the calibration of the single-pass arithmetic is priced once more with (hi, lo) WEIGHTS on fp16
+    activations (2 MFMAs per product; mlt_arith_info.exact == 2) before it falls back to the exact arithmetic: seeds 13 and 24
+    land there, meet the 1e-3 contract against the oracle with the guards on, and give the same bits through every entry point;
+    MLT_NO_W2 is not set in the tests.  Seed 22 fails this tier too (exact), seed 10 never gets to it (fast)."""
+    import oracle
+    pkg = gpu
+    size = 128
+    n = 40
+    org, pred = pkg.synth.make_patches_bulk(size, n, 4711)
+    poc, qp = pkg.synth.make_scalars(n, 4711)
+    org[3] = 512; pred[3] = 512  # a constant CU: flagged by the flat-content guard, re-evaluated exactly
+    for seed in (13, 24):
+        blob = pkg.weights.synthetic_blob(0, seed)
+        m = _ctx(pkg, size, blob)
+        a = m.arithmetic(size)
+        print(f"seed {seed}:", a)
+        assert a["exact"] == 2 and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.75e-3 and a["flat_guard"] == 1
+        ref, ref_split = oracle.Oracle(blob).forward(org, pred, poc, qp, threads=8)
+        s, l = m.predict_batch(org, pred, poc, qp)
+        assert np.abs(l - ref).max() <= LOGIT_TOL
+        assert np.abs(l[3] - ref[3]).max() <= 2e-5, "the constant CU must have been re-run exactly"
+        assert m.arithmetic(size)["guard_reruns"] >= 1
+        sl = head_slices(oracle.Oracle(blob).head_classes)[2]
+        for i in range(n):
+            if decisive(ref[i], sl, 2 * LOGIT_TOL):
+                assert s[i] == ref_split[i]
+        for i in (0, 3, 7):
+            s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+            assert s1 == s[i] and np.array_equal(l1, l[i]), "single-CU graph path differs from the batch path"
+        s2, l2 = m.predict_batch(org[:9], pred[:9], poc[:9], qp[:9])
+        assert np.array_equal(l2, l[:9])
+        m.load_weights(size, pkg.weights.synthetic_blob(0, 10))
+        assert m.arithmetic(size)["exact"] == 0
+        m.close()
+
+
 def test_repeated_runs_bit_identical_128(gpu):
     """The conv kernels synchronise by hand (LDS-DMA landing published by counted vmcnt + barrier, fragment reads behind
     counted lgkmcnt): a missing wait shows up as run-to-run differences.  Ragged batch => partial tiles / tail workgroups."""
