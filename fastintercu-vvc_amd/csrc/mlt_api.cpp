@@ -528,17 +528,15 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       } else if (chain_s2) hout = ho;
       else {
         // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
-        // (t -- the chain's input, fetched by LDS-DMA -- chunk-major as well is opt-in, MLT_T_C16=1: the stride-2 kernel's stores gain
-        // what the chain's DMA loses, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)
-        static const bool t_c16 = std::getenv("MLT_T_C16") != nullptr;
+        // (t -- the chain's input, fetched by LDS-DMA -- stays NHWC: chunk-major, the stride-2 kernel's stores gained what the chain's
+        // DMA lost, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)
         io.ysc_c16 = chain && m.planes[s] == 64 && !no_c16;
-        io.y_c16 = io.ysc_c16 && t_c16;
         if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
         if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
-                             chain_s2 ? cur_c16 : io.y_c16, out_c16, pool[2], io.ysc_c16))) return rc;
+                             cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
         cur = outs[s];
         cur_c16 = out_c16;
         h = hout;

@@ -1588,12 +1588,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       const int sl = pos ^ swz(q);
       int n = (tile << SPW_L) + (q >> (2 * HL));
       n = n < a.n ? n : a.n - 1;  // ragged last tile: a valid sample again (its outputs are masked)
-      // chunk-major input ([n][C/16][HW][16], written so by the producer for ITS stores: one cache line per lane quad): a quad here
-      // covers four slots = two 32-byte chunk pieces = two lines instead of one -- paid under the previous tile's last epilogue
-      const int ch8 = c * KC + sl * 8;
-      const size_t off = a.x_c16 ? ((((size_t)n * (C / 16) + (ch8 >> 4)) << (2 * HL)) + (q & (HW - 1))) * 16 + (ch8 & 8)
-                                 : ((size_t)n * HW + (q & (HW - 1))) * C + ch8;
-      glds16((const char *)a.x + off * 2, smem + c * REGION + piece * 1024);
+      // (NHWC only.  A chunk-major t for the 64-channel chain was tried: its writer's stores gain what this DMA -- four slots of a pixel per
+      // lane quad = two cache lines instead of one -- loses, and the second address form cost this loop a scratch reload per piece)
+      const char *src = (const char *)a.x + (((size_t)n * HW + (q & (HW - 1))) * C + c * KC + sl * 8) * 2;
+      glds16(src, smem + c * REGION + piece * 1024);
     }
   };
 
