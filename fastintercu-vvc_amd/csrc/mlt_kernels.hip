@@ -1366,8 +1366,9 @@ template <class T> __device__ __forceinline__ T karg_reload(size_t off) {
 // registers of the wave that produced it (a wave's output tile covers the same pixels x channels in every conv).  HBM
 // sees t and sc in, out (or only the GAP sums) out: no intermediate is written or re-read, no patch is staged per
 // conv, and three launches become one.
-//   * no halo: a tile is a whole sample, so a tap that leaves the map is conv padding.  The lane reads its own pixel
-//     instead and the fragment is ANDed with an all-zero mask (4 VALU ops per MFMA pair, hidden in the MFMA gaps);
+//   * no halo: a tile is a whole sample, so a tap that leaves the map is conv padding.  Such a lane reads an address beyond the
+//     workgroup's LDS allocation, which returns zeros on gfx950 (CFG_CHAIN_OOBZERO; probed at mlt_init) -- the earlier form, the
+//     lane's own pixel ANDed with a zero mask, cost 8 VALU ops per k-step in the loop where issue slots are scarce (4-6 %);
 //     the buffer is unpadded, 16-byte channel slots XOR-swizzled with the pixel index (conflict-free ds_read_b128 for
 //     16 consecutive pixels, as in the LDS-DMA kernels above);
 //   * weights stream through the same LDS-DMA ring as conv_ring_dma_kernel (first half of the waves), continuously
@@ -1648,40 +1649,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) keep[ps][i][j][qq] = uint4v{0u, 0u, 0u, 0u};
 
-  // L2 prefetch of the NEXT tile's input (whole-stage variant and the single-region 64-channel chain: the buffer the input will be
-  // DMA'd into is busy until the last step, so the request itself cannot be early).  All workgroups run in step, so every CU asks
-  // for its next 128 KiB within the same few microseconds at the end of a tile and then sits waiting (phase stamps: 11 % of the
-  // 64-channel chain at the tile top, 2-4 % per stride-2 step wait of the stages).  The patch waves -- which have no memory wait
-  // inside the last conv -- touch one dword of every 128-byte line of that input during the last conv's first step: the lines
-  // come to L2 / MALL with 10+ us to spare and the LDS-DMA that follows is an L2 hit.  The destination register is never read; it
-  // is kept live (one VGPR, same register for every load: checked in the ISA) up to the vmcnt(0) at the next tile's top.
-#ifndef CFG_CHAIN_L2PF  // measured: no change (64 chain 1.242 -> 1.237 ms, stage step waits 3.3 -> 3.1 %): the waits are not HBM latency.  Off.
-#define CFG_CHAIN_L2PF 0
-#endif
-  constexpr bool L2PF = CFG_CHAIN_L2PF && (S2 || NCHUNK == 1);
-  constexpr int PF_BYTES = S2 ? (CIN * HIN * HIN * 2) << SPW_L : M * C * 2, PF_PER_LANE = PF_BYTES / 128 / (NWP * 64);
-  static_assert(!L2PF || (PF_BYTES % (128 * NWP * 64) == 0 && PF_PER_LANE >= 1 && PF_PER_LANE <= 8), "prefetch split");
-  uint32_t pf_reg = 0;
-  auto l2_prefetch_next = [&](int tile) {
-    if (!patch_wave || ((tile + 1) << SPW_L) > a.n) return;  // (a ragged last tile is not prefetched: the lines behind the buffer are not ours)
-    const char *base = (const char *)a.x + (size_t)tile * PF_BYTES + (size_t)((wave - WP0) * 64 + lane) * 128;
-#pragma unroll
-    for (int k = 0; k < PF_PER_LANE; ++k)
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_reg) : "v"(base + (size_t)k * (NWP * 64 * 128)) : "memory");
-  };
-
-#ifndef CFG_CHAIN_SCPF  // 64-channel chain: the patch waves pull THIS tile's sc (conv 0's residual, fresh from HBM) into L2 during conv 0's first step.
-#define CFG_CHAIN_SCPF 0  // Measured (3 x A/B on one box): launch 1.10 -> 1.11-1.13 ms, the 128 stage behind it 1.05 -> 1.09 ms.  Off.
-#endif
-  constexpr bool SCPF = CFG_CHAIN_SCPF && !KEEP && NCONV == 3 && !S2 && (M * C * 2) % (128 * NWP * 64) == 0;
-  auto l2_prefetch_sc = [&](int tile) {
-    if (!patch_wave) return;
-    const char *base = (const char *)KARG(const void *, cv[0].res) + (size_t)tile * (M * C * 2) + (size_t)((wave - WP0) * 64 + lane) * 128;
-#pragma unroll
-    for (int k = 0; k < (M * C * 2) / 128 / (NWP * 64); ++k)
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_reg) : "v"(base + (size_t)k * (NWP * 64 * 128)) : "memory");
-  };
-
   for (; t < ntiles; t += tstep) {
     // keep the tile loop from turning every tile-invariant address term into a live register (see conv_mfma_kernel)
 #pragma unroll
@@ -1712,14 +1679,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
       if (patch_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PHC_MARK(1);
       asm volatile("s_barrier" ::: "memory");
-      asm volatile("" : "+v"(pf_reg));
       PHC_MARK(0);
     }
     if constexpr (S2) {
       // ================= stride-2 conv + projection shortcut of the stage, on this tile =================
       // patches 0 and 1 and the first weight step of this tile (issued a tile ago / in the prologue; every wave has a share)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      asm volatile("" : "+v"(pf_reg));
       PHC_MARK(0);
       int bS[WPB];  // patch pixel of tap (0, 0) for this lane's output pixels
 #pragma unroll
@@ -1856,12 +1821,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
           const uint32_t pl = lds0 + chunk * REGION;
           auto do_step = [&](int g, auto nitem_c) {
             issue_ring();  // step PFD ahead of the one computed now (into the slot read in step g-1)
-            if constexpr (L2PF && lastc && ps == 0) {
-              if (chunk == 0 && g == 0 && has_next) l2_prefetch_next(t + tstep);
-            }
-            if constexpr (SCPF && cvi == 0 && ps == 0) {
-              if (chunk == 0 && g == 0) l2_prefetch_sc(t);
-            }
             // the last K loop has finished reading region chunk-1: the next sample's input may land there
             if (!S2 && last && has_next && g == 0 && chunk >= 1) dma_region(t + tstep, chunk - 1);
             if (RES == 1 && !RES_LATE && chunk == NCHUNK - 1 && g == NG - 1) {  // HBM residual: flies under the last weight step
@@ -1985,10 +1944,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if constexpr (RES == 1 && RES_LATE) {  // the residual tile requested above (every wave)
-              if (chunk == NCHUNK - 1 && g == NG - 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("" : "+v"(pf_reg));  // (the L2 prefetch loads have landed: their destination register is free from here)
-              }
+              if (chunk == NCHUNK - 1 && g == NG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
 #ifndef KO_CH_BARRIER
             asm volatile("s_barrier" ::: "memory");
@@ -2961,6 +2917,12 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_S2BIG_WP
 #define CFG_S2BIG_WP 4
 #endif
+#ifndef CFG_3264_WP    // 32->64 stride-2 (+shortcut): waves along pixels (tile = 32 * WP pixels) and patch items per lane in registers
+#define CFG_3264_WP 4
+#endif
+#ifndef CFG_3264_UN
+#define CFG_3264_UN 5
+#endif
 #ifndef CFG_3264_WCB   // 32->64 stride-2 (+shortcut)
 #define CFG_3264_WCB 1
 #endif
@@ -3060,7 +3022,7 @@ struct CfgRow { int cin, cout, stride, kc[2], wcb, wpb, wc, wp, gt[2], dma, wpb_
 static const CfgRow kCfg[] = {
     //cin cout s   KC{fast,exact} WCB WPB WC WP  GT{fast,exact}
     {32, 32, 1, {32, 32}, 1, CFG_32_WPB, 1, CFG_32_WP, {9, 3}},
-    {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, 4, {CFG_3264_GT, CFG_GTE_S2}},
+    {32, 64, 2, {32, 32}, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, {CFG_3264_GT, CFG_GTE_S2}},
     {64, 64, 1, {64, 32}, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, {CFG_64_GT, CFG_GTE_S1}, CFG_64_DMA, 0, 0, CFG_LAT},
     {64, 128, 2, {32, 32}, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, {2, CFG_GTE_S2}, CFG_S2A_DMA ? 2 : 0, CFG_S2BIG_WPB, CFG_S2BIG_WP, CFG_LAT},
     {128, 128, 1, {64, 32}, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, {CFG_BIG_GT, CFG_GTE_S1}, CFG_BIG_DMA ? 2 : 0, CFG_BIG_DMA_WPB, CFG_BIG_DMA_WP, CFG_LAT},
@@ -3151,7 +3113,7 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
     return launch_conv_t<64, 64, 1, 9, false, 64, 1, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 9, 1, CFG_64_DMA_UN, CFG_S1_MINW, true>(a, grid_x, extra_lds, st);
 #endif
   CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
-  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, 4, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, 5, 3, CFG_32_MINW)
+  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, CFG_3264_UN, 3, CFG_32_MINW)
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, CFG_GTE_S1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
   CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_GTE_S2, 2, 2, 5, 3, CFG_S2_MINW)
   CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, CFG_GTE_S1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)

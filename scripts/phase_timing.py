@@ -47,7 +47,7 @@ lib.mlt_debug_phase_read_chain(cbuf, 0)
 cnames = ["tile top: wait for patches 0/1 + first weight step (64 chain: barrier after own vmcnt wait)", "S2 steps: reads + MFMA (64 chain: own wait for the input DMA at the tile top)", "S2 steps: end wait + barrier", "S2 epilogue (bias, t -> LDS, sc -> regs, barrier)",
           "conv 0 steps: reads + MFMA", "conv 0 steps: end wait + barrier", "conv 0 epilogue", "conv 1 steps: reads + MFMA", "conv 1 steps: end wait + barrier",
           "conv 1 epilogue", "conv 2 steps: reads + MFMA", "conv 2 steps: end wait + barrier", "conv 2 epilogue (HBM / GAP) + next tile's patch DMA issue"]
-for cid, nm in enumerate(["chain 128@16 or 64@32 (MLT_CHAIN64=1)", "stage 128@16 (S2)", "chain 256@8", "stage 256@8 (S2)"]):
+for cid, nm in enumerate(["64-channel chain (default) or chain 128@16 (MLT_NO_CHAIN_S2=1)", "stage 128@16 (S2)", "chain 256@8", "stage 256@8 (S2)"]):
     row = [cbuf[cid * 16 + i] for i in range(16)]
     tot = sum(row)
     if not tot:
