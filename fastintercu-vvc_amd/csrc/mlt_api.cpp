@@ -120,6 +120,7 @@ struct mlt_ctx {
   size_t gstage_bytes = 0;
   std::string err;
   bool profile = false;
+  bool lds_oob_zero = false;  // DS reads beyond the LDS allocation return zeros on this device (probed at init): chain kernels without zero masks
   bool w2_now = false;  // the network being enqueued runs an exact-packed model with hi+lo WEIGHTS only (2 MFMAs, single activation planes)
   std::map<std::string, ProfAcc> prof;
   std::vector<std::string> prof_order;
@@ -437,7 +438,7 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, a, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
   return MLT_OK;
@@ -915,20 +916,22 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     return MLT_ERR_NOMEM;
   }
   ctx->own_stream = true;
-  if (mlt_chain_reads_beyond_lds()) {
-    // the chain kernels take conv padding from DS reads beyond the LDS allocation (zeros on gfx950): verify, once per context,
-    // that this device behaves so -- (ab)using the zero page as the 4-byte result slot, restored afterwards
+  {
+    // the chain kernels take conv padding from DS reads beyond the LDS allocation (zeros on gfx950) instead of zero masks: probe, once
+    // per context, that this device behaves so -- (ab)using the zero page as the 4-byte result slot, restored afterwards; a device that
+    // does not (or MLT_NO_LDS_OOB=1) gets the masked form of the same kernels
     int ok = 0;
-    const bool ran = mlt_probe_lds_oob((int *)ctx->zero_page, ctx->stream) == hipSuccess &&
+    const bool ran = std::getenv("MLT_NO_LDS_OOB") == nullptr && mlt_probe_lds_oob((int *)ctx->zero_page, ctx->stream) == hipSuccess &&
                      hipMemcpyAsync(&ok, ctx->zero_page, sizeof ok, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                     hipMemsetAsync(ctx->zero_page, 0, sizeof ok, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    if (!ran || !ok) {
-      g_init_error = ran ? "this device does not return zeros for LDS reads beyond the allocation (rebuild with -DCFG_CHAIN_OOBZERO=0)" : "LDS probe launch failed";
+                     hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (hipMemsetAsync(ctx->zero_page, 0, sizeof ok, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      g_init_error = "zero page reset failed";
       (void)hipFree(ctx->zero_page);
       (void)hipStreamDestroy(ctx->stream);
       delete ctx;
       return MLT_ERR_HIP;
     }
+    ctx->lds_oob_zero = ran && ok == 1;
   }
   const uint32_t mask = cfg->size_mask ? cfg->size_mask : MLT_SIZE_128;  // reference gate: 128 only (EncCu.cpp:754)
   static const int sizes[4] = {128, 64, 32, 16};

@@ -106,10 +106,9 @@ struct ChainArgs {
   int gap_slots, gap_l;
   int n;
 };
-hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, const ChainArgs &a, int grid_x, hipStream_t st);  // oob_zero: see mlt_probe_lds_oob
 bool mlt_chain_supported(int c, int h);
 hipError_t mlt_probe_lds_oob(int *d_ok, hipStream_t st);  // *d_ok = 1 iff DS reads beyond the LDS allocation return zeros on this device
-bool mlt_chain_reads_beyond_lds();                         // the chain kernels were built to rely on that (CFG_CHAIN_OOBZERO)
 bool mlt_stage_supported(int c, int h);  // ... including the stage's stride-2 conv + shortcut (S2 variant)
 
 struct HeadArgs {

@@ -1367,7 +1367,7 @@ template <class T> __device__ __forceinline__ T karg_reload(size_t off) {
 // sees t and sc in, out (or only the GAP sums) out: no intermediate is written or re-read, no patch is staged per
 // conv, and three launches become one.
 //   * no halo: a tile is a whole sample, so a tap that leaves the map is conv padding.  Such a lane reads an address beyond the
-//     workgroup's LDS allocation, which returns zeros on gfx950 (CFG_CHAIN_OOBZERO; probed at mlt_init) -- the earlier form, the
+//     workgroup's LDS allocation, which returns zeros on gfx950 (OOBZ; probed at mlt_init, which selects the masked form of the kernel otherwise) -- the earlier form, the
 //     lane's own pixel ANDed with a zero mask, cost 8 VALU ops per k-step in the loop where issue slots are scarce (4-6 %);
 //     the buffer is unpadded, 16-byte channel slots XOR-swizzled with the pixel index (conflict-free ds_read_b128 for
 //     16 consecutive pixels, as in the LDS-DMA kernels above);
@@ -1392,7 +1392,7 @@ template <class T> __device__ __forceinline__ T karg_reload(size_t off) {
 //     a wave owns 64 couts x 128 pixels = 8 accumulators = 128 VGPRs): no room to keep b0 in registers -- conv 0 also writes it
 //     to HBM (ChainConv.y) and the last conv reads it back (L2-hot) as an ordinary residual, both loaded AFTER the last step's
 //     MFMA loop.  One channel chunk only, so the next sample's input can be fetched only after the last step of the last conv.
-template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false, bool KEEP = true>
+template <int C, int HL, int SPW_L, int WCB, int WPB, int WAVES_C, int WAVES_P, int GT, int RB, int FD, int MINW, int NCONV, bool SPLIT_ROLES, bool S2 = false, bool KEEP = true, bool OOBZ = false>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(const ChainArgs a) {
   constexpr int KC = 64, NCHUNK = C / KC, KS = KC / 16, SLOTS = KC / 8, TAPS = 9, NG = (TAPS + GT - 1) / GT, GT_LAST = TAPS - (NG - 1) * GT;  // a last, shorter tap group when GT does not divide 9
   constexpr int CBT = WCB * WAVES_C, CT = 32 * CBT, NPASS = C / CT, NW = WAVES_C * WAVES_P;
@@ -1467,9 +1467,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
 #ifndef CFG_CHAIN_SWZ16
 #define CFG_CHAIN_SWZ16 1
 #endif
-#ifndef CFG_CHAIN_OOBZERO  // 1: a tap outside the map reads an LDS address beyond the allocation (DS reads out of range return 0) instead of
-#define CFG_CHAIN_OOBZERO 1  //    the lane's own pixel ANDed with a zero mask (8 VALU ops per k-step and wave: knock-out -4..6 % per launch)
-#endif
+  // OOBZ: a tap outside the map reads an LDS address beyond the allocation (DS reads out of range return 0 on gfx950) instead of the
+  // lane's own pixel ANDed with a zero mask (8 VALU ops per k-step and wave: knock-out -4..6 % per launch).  Both forms are built for the
+  // three kernels of the default path; the context picks per device (mlt_probe_lds_oob at mlt_init).
 #ifndef CFG_CHAIN_SWZ32  // 32-wide maps: 0 = no extra bit.  A read window of a dx = +-1 tap crosses a 16-pixel boundary there, and any
 #define CFG_CHAIN_SWZ32 0  // term that depends on bit 4 of q then maps two same-parity pixels of the window to one slot (2-way conflict on 6 of 9 taps)
 #endif
@@ -1848,9 +1848,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                     const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H;  // else: conv padding
                     const int q = ok ? pj[j] + (dy - 1) * H + (dx - 1) : pj[j];
                     rowa[j] = pl + q * (KC * 2);
-#if CFG_CHAIN_OOBZERO
-                    if (!ok) rowa[j] = 0x100000u;  // beyond the LDS: the read returns zeros, no mask needed
-#endif
+                    if constexpr (OOBZ) {
+                      if (!ok) rowa[j] = 0x100000u;  // beyond the LDS: the read returns zeros, no mask needed
+                    }
                     hs[j] = (h * 16) ^ (swz(q) << 4);
                     mcur[j] = ok ? 0xFFFFFFFFu : 0u;
                   }
@@ -1885,9 +1885,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 for (int j = 0; j < WPB; ++j) {
                   lds_touch(fb[sl][j]);
                   bm[j] = fb[sl][j];
-#if !defined(KO_CH_MASK) && !CFG_CHAIN_OOBZERO
+#if !defined(KO_CH_MASK)
+                  if constexpr (!OOBZ) {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
+                    for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
+                  }
 #endif
                 }
 #pragma unroll
@@ -3127,9 +3129,9 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
 
 // fused chain kernels: (channels, map height) -> instantiation.  128@16: one sample per 16-wave workgroup, weights packed for
 // 128-cout tiles / 64-channel chunks / 3 taps per step (the stand-alone layer's packing).
-// ---- LDS out-of-range probe: chain_kernel (CFG_CHAIN_OOBZERO) lets a tap outside the map read beyond the LDS allocation and relies on
+// ---- LDS out-of-range probe: chain_kernel<..., OOBZ = true> lets a tap outside the map read beyond the LDS allocation and relies on
 // the hardware returning zeros for such a DS read.  One workgroup with the chain kernels' full 160 KiB allocation reads where they do;
-// *ok = 1 iff every lane saw zeros.  Run once per context at mlt_init: a device that answers differently is refused there. ----
+// *ok = 1 iff every lane saw zeros.  Run once per context at mlt_init: a device that answers differently gets the masked kernels. ----
 __global__ __launch_bounds__(64) void lds_oob_probe_kernel(int *ok) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -3151,7 +3153,6 @@ hipError_t mlt_probe_lds_oob(int *d_ok, hipStream_t st) {
   hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(64), 160 * 1024, st, d_ok);
   return hipGetLastError();
 }
-bool mlt_chain_reads_beyond_lds() { return CFG_CHAIN_OOBZERO != 0; }
 
 bool mlt_chain_supported(int c, int h) { return (c == 64 && h == 32) || (c == 128 && h == 16) || (c == 256 && h == 8); }
 bool mlt_stage_supported(int c, int h) { return (c == 128 && h == 16) || (c == 256 && h == 8); }  // whole-stage (S2) variant
@@ -3170,22 +3171,31 @@ template <class K> static hipError_t launch_chain_t(K kern, DeviceOnce &once, co
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3(threads), lds, st, a);
   return hipGetLastError();
 }
-hipError_t mlt_launch_chain(int c, int h, bool with_s2, const ChainArgs &a, int grid_x, hipStream_t st) {
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, const ChainArgs &a, int grid_x, hipStream_t st) {
   static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel reads the packing of the stand-alone 128->128 / 256->256 layers");
   constexpr int lds = 64 * 1024 + 2 * (CFG_BIG_GT * 4 * 4 * 1024);  // 64 KiB activation + two 48 KiB weight steps = all of the LDS
-  static DeviceOnce once[6];
-  if (c == 64 && h == 32 && a.nconv == 3 && !with_s2) {  // 8 waves x (64 couts x 128 pixels), one 128 KiB sample per workgroup, 4 x 8 KiB weight ring
+  static DeviceOnce once[10];
+  // oob_zero: conv padding from DS reads beyond the LDS allocation (the probed default) or from zero masks; the kernels off the default path
+  // (chains without the stride-2 front conv, MLT_NO_CHAIN_S2) exist in the masked form only
+  if (c == 64 && h == 32 && a.nconv == 3 && !with_s2) {  // 8 waves x (64 couts x 128 pixels), one 128 KiB sample per workgroup, 2 x 16 KiB weight ring
     static_assert(CFG_64_WCB == 2 && CFG_64_WC == 1 && CFG_64_GT == 9, "chain_kernel<64,...> reads the packing of the stand-alone 64->64 layer");
-    static DeviceOnce once64;
-    return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, CFG_CHAIN64_GT, CFG_CHAIN64_GT == 1 ? 4 : 2, 1, 2, 3, true, false, false>, once64, a, grid_x, 512, 128 * 1024 + 4 * 8 * 1024, st);
+    constexpr int RB64 = CFG_CHAIN64_GT == 1 ? 4 : 2, lds64 = 128 * 1024 + 4 * 8 * 1024;
+    if (oob_zero) return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, CFG_CHAIN64_GT, RB64, 1, 2, 3, true, false, false, true>, once[6], a, grid_x, 512, lds64, st);
+    return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, CFG_CHAIN64_GT, RB64, 1, 2, 3, true, false, false, false>, once[7], a, grid_x, 512, lds64, st);
   }
   if (c == 128 && h == 16) {  // 8 waves x (64 couts x 64 pixels), one sample per workgroup
-    if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[4], a, grid_x, 512, lds, st);
+    if (with_s2 && a.nconv == 3) {
+      if (oob_zero) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true, true, true>, once[4], a, grid_x, 512, lds, st);
+      return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true, true, false>, once[8], a, grid_x, 512, lds, st);
+    }
     if (a.nconv == 3) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[0], a, grid_x, 512, lds, st);
     if (a.nconv == 2) return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[1], a, grid_x, 512, lds, st);
   }
   if (c == 256 && h == 8) {   // 8 waves x (64 couts x 32 pixels) x 2 cout passes, two samples per workgroup
-    if (with_s2 && a.nconv == 3) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true>, once[5], a, grid_x, 512, lds, st);
+    if (with_s2 && a.nconv == 3) {
+      if (oob_zero) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true, true, true>, once[5], a, grid_x, 512, lds, st);
+      return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, true, true, true, false>, once[9], a, grid_x, 512, lds, st);
+    }
     if (a.nconv == 3) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 3, CFG_CHAIN_SPLIT != 0>, once[2], a, grid_x, 512, lds, st);
     if (a.nconv == 2) return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, CFG_CHAIN_FD, 2, 2, CFG_CHAIN_SPLIT != 0>, once[3], a, grid_x, 512, lds, st);
   }

@@ -411,6 +411,25 @@ def test_kernel_variant_switches_do_not_change_results(gpu):
     m.close()
 
 
+def test_padding_from_beyond_the_lds_equals_the_masked_kernels(gpu, monkeypatch):
+    """The chain / whole-stage kernels take conv padding from DS reads beyond the LDS allocation (zeros on gfx950; probed per context at
+    mlt_init) instead of zero masks.  A context made with MLT_NO_LDS_OOB=1 runs the masked form of the same kernels -- what a device
+    that fails the probe would get: same bits."""
+    pkg = gpu
+    size, n = 128, 70  # above every switch point of the 64- and 128-channel stages, two half-filled tiles for the 256 stage
+    blob = pkg.weights.synthetic_blob(0, 10)
+    org, pred = pkg.synth.make_patches_bulk(size, n, 8)
+    poc, qp = pkg.synth.make_scalars(n, 8)
+    m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)
+    s0, l0 = m.predict_batch(org, pred, poc, qp)
+    m.close()
+    monkeypatch.setenv("MLT_NO_LDS_OOB", "1")
+    mm = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)
+    s1, l1 = mm.predict_batch(org, pred, poc, qp)
+    mm.close()
+    assert np.array_equal(l0, l1) and np.array_equal(s0, s1)
+
+
 def test_head_index_option_and_errors(gpu):
     pkg = gpu
     blob = pkg.weights.synthetic_blob(1, 10)

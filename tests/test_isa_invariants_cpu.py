@@ -13,9 +13,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
-STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
-STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true>"
-CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 2, 2, 1, 2, 3, true, false, false>"
+STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s>"
+STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s>"
+CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 2, 2, 1, 2, 3, true, false, false, %s>"
+FORMS = ("true", "false")  # conv padding from beyond the LDS (the probed default) / from zero masks (fallback)
 
 
 @pytest.fixture(scope="module")
@@ -32,8 +33,10 @@ def _find(stats, prefix):
     return hits[0]
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("kernel", [STAGE_128, STAGE_256])
-def test_whole_stage_kernels_have_no_scratch_and_no_compiler_drain_in_loops(stats, kernel):
+def test_whole_stage_kernels_have_no_scratch_and_no_compiler_drain_in_loops(stats, kernel, form):
+    kernel = kernel % form
     st = _find(stats, kernel)
     assert st["scratch"] == 0, f"{kernel}: {st['scratch']} scratch ops (register spills)"
     inner = [w for w in st["waits"] if w[1] >= 1]
@@ -41,8 +44,9 @@ def test_whole_stage_kernels_have_no_scratch_and_no_compiler_drain_in_loops(stat
     assert st["glds"] > 50  # the LDS-DMA staging is there (guards against matching a different kernel)
 
 
-def test_64_channel_chain_spills_stay_out_of_the_step_loops(stats):
-    st = _find(stats, CHAIN_64)
+@pytest.mark.parametrize("form", FORMS)
+def test_64_channel_chain_spills_stay_out_of_the_step_loops(stats, form):
+    st = _find(stats, CHAIN_64 % form)
     assert st["scratch"] <= 8, f"{st['scratch']} scratch ops (round 2: 4, all at the tile end)"
     deep = [w for w in st["waits"] if w[1] >= 2]
     assert not deep, f"compiler-generated vmcnt waits inside the step loops: {deep[:5]}"
