@@ -158,6 +158,16 @@ KIND_ZERO_RESI = 2   # pred == org  (all-zero residual channel)
 KIND_SATURATED = 3   # org = 1023, pred = 0 on a checkerboard, swapped elsewhere
 KIND_FLAT = 4        # constant org, constant pred
 KIND_OUT_OF_RANGE = 5  # texture with 2 % of the samples replaced by negative / > 10-bit Pel values (uint16 cast + clip path)
+# content the flat-content guard does not see, or sees only in part (round 3; real video: sky, letterbox edges, screen content)
+KIND_PARTIAL_FLAT = 6      # texture with an exactly-constant rectangle over 10-12 % of the aligned quads (just UNDER the guard's 1/8)
+KIND_ORG_FLAT_PRED_TEX = 7 # constant org, textured pred (one coherent plane only)
+KIND_ORG_TEX_PRED_FLAT = 8 # textured org, constant pred
+KIND_RAMP = 9              # smooth horizontal / diagonal luma ramps, pred = the ramp shifted by one or two pixels
+KIND_DITHER = 10           # constant +- 1 LSB dither in both planes
+KIND_LOW_CONTRAST = 11     # texture of amplitude <= 4 on a constant base, pred = org + noise[-2,2]
+KIND_FLAT_ZERO_RESI = 12   # constant org and pred == org (zero residual on flat content)
+KIND_NAMES = {0: "texture", 1: "uniform", 2: "zero_resi", 3: "saturated", 4: "flat", 5: "out_of_range", 6: "partial_flat",
+              7: "org_flat_pred_tex", 8: "org_tex_pred_flat", 9: "ramp", 10: "dither", 11: "low_contrast", 12: "flat_zero_resi"}
 
 
 def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, first: int = 0):
@@ -200,6 +210,46 @@ def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, f
         elif kind == KIND_FLAT:
             o = np.full((size, size), int(randint(input_seed, tag + "/o", 1, 0, 1023)[0]), dtype=np.int64)
             p = np.full((size, size), int(randint(input_seed, tag + "/p", 1, 0, 1023)[0]), dtype=np.int64)
+        elif kind in (KIND_PARTIAL_FLAT, KIND_ORG_FLAT_PRED_TEX, KIND_ORG_TEX_PRED_FLAT):
+            nb = max(size // 16, 1)
+            base = randint(input_seed, tag + "/base", nb * nb, 64, 959).reshape(nb, nb)
+            base = np.kron(base, np.ones((size // nb, size // nb), dtype=np.int64))
+            o = np.clip(base + randint(input_seed, tag + "/tex", px, -48, 48).reshape(size, size), 0, 1023)
+            p = np.clip(o + randint(input_seed, tag + "/noise", px, -40, 40).reshape(size, size), 0, 1023)
+            co = int(randint(input_seed, tag + "/co", 1, 0, 1023)[0])
+            cp = int(randint(input_seed, tag + "/cp", 1, 0, 1023)[0])
+            if kind == KIND_PARTIAL_FLAT:
+                # rows [r0, r0 + hh) x all columns constant in BOTH planes: hh / size in [10 %, 12.5 %) of the quads
+                hh = max((size * (10 + idx % 3)) // 100, 1)
+                if hh * 8 >= size:
+                    hh = max(size // 8 - 1, 1)
+                r0 = int(randint(input_seed, tag + "/r0", 1, 0, size - hh)[0])
+                o[r0:r0 + hh, :] = co
+                p[r0:r0 + hh, :] = cp
+            elif kind == KIND_ORG_FLAT_PRED_TEX:
+                o[:, :] = co
+            else:
+                p[:, :] = cp
+        elif kind == KIND_RAMP:
+            yy, xx = np.mgrid[0:size, 0:size]
+            a = int(randint(input_seed, tag + "/a", 1, 0, 400)[0])
+            sx = int(randint(input_seed, tag + "/sx", 1, 1, 4)[0])   # luma steps per pixel (x4 fixed point below)
+            sy = int(randint(input_seed, tag + "/sy", 1, 0, 4)[0]) if idx % 2 else 0   # odd patches: diagonal
+            o = np.clip(a + (sx * xx + sy * yy) * max(512 // size, 1) // 4, 0, 1023)
+            sh = 1 + idx % 2
+            p = np.clip(a + (sx * (xx + sh) + sy * (yy + sh)) * max(512 // size, 1) // 4, 0, 1023)
+        elif kind == KIND_DITHER:
+            co = int(randint(input_seed, tag + "/co", 1, 1, 1022)[0])
+            cp = int(randint(input_seed, tag + "/cp", 1, 1, 1022)[0])
+            o = co + randint(input_seed, tag + "/do", px, -1, 1).reshape(size, size)
+            p = cp + randint(input_seed, tag + "/dp", px, -1, 1).reshape(size, size)
+        elif kind == KIND_LOW_CONTRAST:
+            co = int(randint(input_seed, tag + "/co", 1, 8, 1015)[0])
+            o = co + randint(input_seed, tag + "/tex", px, -4, 4).reshape(size, size)
+            p = np.clip(o + randint(input_seed, tag + "/noise", px, -2, 2).reshape(size, size), 0, 1023)
+        elif kind == KIND_FLAT_ZERO_RESI:
+            o = np.full((size, size), int(randint(input_seed, tag + "/o", 1, 0, 1023)[0]), dtype=np.int64)
+            p = o.copy()
         else:
             raise ValueError(kind)
         org[i] = o.astype(np.int16)

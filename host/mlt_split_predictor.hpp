@@ -10,9 +10,16 @@
 //                          no-op (EncModeCtrl.cpp:147-148) and the encoder runs its exhaustive RDO.
 // Header-only; link with -lmltcnn_hip.  One instance per EncCu (the encoder is single-threaded, or one EncCu per
 // thread under WPP / split parallelism, EncCu.cpp:233).
+//
+// Test hooks (environment, read once per instance; none is needed in production):
+//   MLTCNN_FAULT_INJECT=1      the predictor reports ok() without touching a device and every predictSplitMode() fails (-1):
+//                              exercises the reference's swallow-and-continue contract from the real call site on a box without a GPU
+//   MLTCNN_CALL_DUMP_FILE=path every predictSplitMode() call is appended to `path` (little-endian records, see dumpCall):
+//                              tests/test_vtm_encoder.py re-checks each one against the CPU oracle
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../include/mltcnn.h"
@@ -37,6 +44,9 @@ class SplitPredictor {
     cfg.guard_margin = 0.f;  // default threshold when MLT_FLAG_DECISION_GUARD is set
     cfg.tolerance = 0.f;     // default |dlogit| contract (1e-3) for the load-time calibration of the fast arithmetic
     m_mask = sizeMask ? sizeMask : MLT_SIZE_128;
+    if (const char *d = std::getenv("MLTCNN_CALL_DUMP_FILE")) m_dumpPath = d;
+    if (const char *f = std::getenv("MLTCNN_FAULT_INJECT")) m_faultInject = std::atoi(f) != 0;
+    if (m_faultInject) return;
     const int rc = mlt_init(&cfg, &m_ctx);
     if (rc != MLT_OK) {
       std::fprintf(stderr, "error loading the model\n");  // the reference's message (EncCu.cpp:904)
@@ -48,7 +58,7 @@ class SplitPredictor {
   SplitPredictor(const SplitPredictor &) = delete;
   SplitPredictor &operator=(const SplitPredictor &) = delete;
 
-  bool ok() const { return m_ctx != nullptr; }
+  bool ok() const { return m_ctx != nullptr || m_faultInject; }
 
   // EncCu.cpp:746-756.  chType: partitioner.chType (0 = luma / joint tree); isIntraSlice: slice type == I_SLICE;
   // (cux, cuy, cuw, cuh): tempCS->area.Y(); (picW, picH): slice->getPic()->Y().
@@ -64,11 +74,13 @@ class SplitPredictor {
   // or -1 on any failure.
   int predictSplitMode(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, float *logitsOpt = nullptr) {
     int32_t split = -1;
-    if (!m_ctx) return -1;
-    if (mlt_predict(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, &split, logitsOpt) != MLT_OK) {
+    float lg[MLT_MAX_LOGITS] = {0};
+    if (!m_ctx || mlt_predict(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, &split, (logitsOpt || !m_dumpPath.empty()) ? lg : nullptr) != MLT_OK) {
       std::fprintf(stderr, "error\n");  // EncCu.cpp:925
-      return -1;
+      split = -1;
     }
+    if (logitsOpt) for (int i = 0; i < mlt_num_logits(cuw); ++i) logitsOpt[i] = lg[i];
+    if (!m_dumpPath.empty()) dumpCall(org, orgStride, pred, predStride, cuw, poc, cuQP, split, lg);
     return split;
   }
 
@@ -88,8 +100,25 @@ class SplitPredictor {
   }
 
  private:
+  // one record per call: int32 {magic 0x4D4C5443, cuw, poc, qp, split, nLogits}, float logits[MLT_MAX_LOGITS], int16 org[cuw*cuw], int16 pred[cuw*cuw]
+  void dumpCall(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, int split, const float *lg) const {
+    std::FILE *f = std::fopen(m_dumpPath.c_str(), "ab");
+    if (!f) return;
+    const int32_t hdr[6] = {0x4D4C5443, cuw, poc, cuQP, split, mlt_num_logits(cuw)};
+    std::fwrite(hdr, sizeof hdr, 1, f);
+    std::fwrite(lg, sizeof(float), MLT_MAX_LOGITS, f);
+    for (int pl = 0; pl < 2; ++pl)
+      for (int y = 0; y < cuw; ++y) {
+        const Pel *src = (pl ? pred : org) + (ptrdiff_t)y * (pl ? predStride : orgStride);
+        std::fwrite(src, sizeof(Pel), (size_t)cuw, f);
+      }
+    std::fclose(f);
+  }
+
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;
+  bool m_faultInject = false;
+  std::string m_dumpPath;
 };
 
 }  // namespace mlt

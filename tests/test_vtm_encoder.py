@@ -1,0 +1,143 @@
+"""The N1 integration patch LINKED and RUN: the reference encoder (VTM-11.0 + the authors' CNN call site), patched with
+patches/vtm-mlt-cpp-mltcnn.patch and built against include/ + host/ + libmltcnn_hip.so by tools/build_vtm.sh (build container
+only; the binaries live in the git-ignored oracle/_ref/vtm/ and travel to the GPU box with the snapshot).  Every test is
+skipped where the binary is absent.
+
+CPU (no device):  the reference's swallow-and-continue contract (EncCu.cpp:902-905,923-926; EncModeCtrl.cpp:147-148) from the
+                  REAL call site -- a failing predictor (-1 for every CU), a missing device and a predictor with no CU size
+                  enabled (= stock VTM-11.0 RDO) must all write the same bitstream, and the decoder reproduces the reconstruction.
+GPU  (-m gpu):    the same encode with seed-10 weights: every predictSplitMode() call the encoder made (org / pred planes out of
+                  VTM's picture buffers with their real strides, POC, CU QP) is dumped by host/mlt_split_predictor.hpp and re-checked
+                  against the CPU oracle (|dlogit| <= 1e-3, same split where decisive); the bitstream decodes to the encoder's
+                  reconstruction.
+Input: tools/make_synth_yuv.py (384 x 256, 10-bit 4:2:0, 3 frames: moving texture + constant / ramp / low-contrast CTUs), coded
+with tests/data/vtm_ldb_small.cfg (CTU 128, low-delay B, QP 32)."""
+import hashlib
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VTM = os.path.join(ROOT, "oracle", "_ref", "vtm")
+ENC, DEC = os.path.join(VTM, "EncoderApp"), os.path.join(VTM, "DecoderApp")
+CFG = os.path.join(ROOT, "tests", "data", "vtm_ldb_small.cfg")
+W, H, FRAMES = 384, 256, 3
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(ENC) and os.path.exists(DEC)),
+                                reason="patched EncoderApp not built (tools/build_vtm.sh, build container only)")
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "fastintercu-vvc_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+    for k in ("MLTCNN_FAULT_INJECT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def _yuv(tmp):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synth_yuv
+    path = os.path.join(tmp, "synth.yuv")
+    make_synth_yuv.write_yuv(path, make_synth_yuv.make_frames(W, H, FRAMES, 7))
+    return path
+
+
+def _encode_cmd(yuv, tag, tmp):
+    return [ENC, "-c", CFG, "-i", yuv, "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-f", str(FRAMES), "--InputBitDepth=10",
+            "--InputChromaFormat=420", "-q", "32", "-b", os.path.join(tmp, tag + ".bin"), "-o", os.path.join(tmp, tag + "_rec.yuv")]
+
+
+def _decode_matches_recon(tmp, tag):
+    out = os.path.join(tmp, tag + "_dec.yuv")
+    r = subprocess.run([DEC, "-b", os.path.join(tmp, tag + ".bin"), "-o", out, "-d", "10"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "(OK)" in r.stdout and "ERROR" not in r.stdout.upper().replace("(OK)", ""), r.stdout[-2000:]   # SEI picture hashes verified
+    assert open(out, "rb").read() == open(os.path.join(tmp, tag + "_rec.yuv"), "rb").read()
+
+
+def test_failed_inference_means_full_rdo_from_the_real_call_site(tmp_path):
+    """-1 => EncModeCtrl::setNewModeList is a no-op => exhaustive RDO: bitstream == the encode with the CNN gated off."""
+    tmp = str(tmp_path)
+    yuv = _yuv(tmp)
+    runs = {"inject": _env(MLTCNN_FAULT_INJECT="1"),      # gate passes, every predictSplitMode() returns -1 ("error" + "Hello")
+            "nodevice": _env(),                           # mlt_init fails here (no GPU): ok() false, gate never passes
+            "anchor": _env(MLTCNN_SIZE_MASK="0x100")}     # no CU size enabled: stock VTM-11.0 mode decision
+    procs = {k: subprocess.Popen(_encode_cmd(yuv, k, tmp), env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k, e in runs.items()}
+    logs = {k: p.communicate(timeout=900)[0] for k, p in procs.items()}
+    for k, p in procs.items():
+        assert p.returncode == 0, logs[k][-3000:]
+    # the reference's own messages: "error" from the failed inference (EncCu.cpp:925), "Hello" from setNewModeList(-1) (EncModeCtrl.cpp:148)
+    assert logs["inject"].count("Hello") >= 2 * 6 and logs["inject"].count("error\n") == logs["inject"].count("Hello")
+    assert logs["anchor"].count("Hello") == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert "no usable HIP device" in logs["nodevice"] and logs["nodevice"].count("Hello") == 0
+    sha = {k: hashlib.sha256(open(os.path.join(tmp, k + ".bin"), "rb").read()).hexdigest() for k in runs}
+    assert sha["inject"] == sha["anchor"], sha
+    if not torch.cuda.is_available():
+        assert sha["nodevice"] == sha["anchor"], sha
+    _decode_matches_recon(tmp, "inject")
+
+
+def read_call_dump(path):
+    """Records written by mlt::SplitPredictor::dumpCall (host/mlt_split_predictor.hpp)."""
+    out = []
+    with open(path, "rb") as f:
+        while True:
+            hdr = f.read(24)
+            if len(hdr) < 24:
+                break
+            magic, cuw, poc, qp, split, nl = struct.unpack("<6i", hdr)
+            assert magic == 0x4D4C5443
+            lg = np.frombuffer(f.read(15 * 4), "<f4")[:nl].copy()
+            org = np.frombuffer(f.read(cuw * cuw * 2), "<i2").reshape(cuw, cuw).copy()
+            pred = np.frombuffer(f.read(cuw * cuw * 2), "<i2").reshape(cuw, cuw).copy()
+            out.append(dict(cuw=cuw, poc=poc, qp=qp, split=split, logits=lg, org=org, pred=pred))
+    return out
+
+
+@pytest.mark.gpu
+def test_encode_on_the_gpu_every_call_matches_the_oracle(pkg, tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    from oracle import Oracle
+    from helpers import decisive, head_slices
+    tmp = str(tmp_path)
+    yuv = _yuv(tmp)
+    blob = pkg.weights.synthetic_blob(pkg.synth.ARCH_CTU, 10)
+    wdir = os.path.join(tmp, "torch_model")
+    os.makedirs(wdir)
+    open(os.path.join(wdir, "MLTORPQ_splitMode_128.mltw"), "wb").write(blob)
+    dump = os.path.join(tmp, "calls.bin")
+    r = subprocess.run(_encode_cmd(yuv, "gpu", tmp), env=_env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_CALL_DUMP_FILE=dump), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "error" not in r.stderr and r.stdout.count("Hello") == 0, r.stderr[-2000:]   # no failed inference, no -1 reached setNewModeList
+    calls = read_call_dump(dump)
+    assert len(calls) >= 2 * 6, len(calls)           # 6 fully-inside CTUs in each of the 2 inter pictures (more when several QPs are tried)
+    assert all(c["cuw"] == 128 and c["split"] in (0, 1, 2, 3) for c in calls)
+    assert {c["poc"] for c in calls} == {1, 2}
+    orc = Oracle(blob)
+    org = np.stack([c["org"] for c in calls]); pred = np.stack([c["pred"] for c in calls])
+    poc = np.array([c["poc"] for c in calls], np.int32); qp = np.array([c["qp"] for c in calls], np.int32)
+    ref, ref_split = orc.forward(org, pred, poc, qp, threads=8)
+    got = np.stack([c["logits"] for c in calls])
+    err = float(np.abs(got - ref).max())
+    sl = head_slices(orc.head_classes)[2]
+    nd = 0
+    for i, c in enumerate(calls):
+        if decisive(ref[i], sl, 2e-3):
+            assert c["split"] == ref_split[i], (i, c["split"], ref_split[i])
+        else:
+            nd += 1
+    flat = sum(1 for c in calls if (c["org"] == c["org"][0, 0]).all())
+    print(f"VTM encode on the GPU: {len(calls)} predictSplitMode calls, max|dlogit| vs oracle {err:.2e}, splits {np.bincount([c['split'] for c in calls], minlength=4).tolist()}, "
+          f"{nd} non-decisive, {flat} exactly-constant CUs")
+    assert err <= 1e-3, err
+    assert flat >= 2   # the constant CTU really reached the predictor (flat-content guard path inside mlt_predict)
+    _decode_matches_recon(tmp, "gpu")

@@ -14,6 +14,7 @@ What the patch does (reference lines):
   source/Lib/EncoderLib/EncCu.cpp:928       m_modeCtrl->setNewModeList(...)  UNTOUCHED
   source/Lib/EncoderLib/EncCu.h             forward declaration + member
   CMakeLists.txt:58-66, source/Lib/EncoderLib/CMakeLists.txt:35-40   Torch / OpenCV stanzas -> MLTCNN_ROOT include dirs + libmltcnn_hip.so
+  source/Lib/EncoderLib/EncSlice.cpp:51-54  four unused OpenCV includes removed
 
 usage: python tools/make_vtm_patch.py [--ref /root/reference/vtm-mlt-cpp] [--out patches/vtm-mlt-cpp-mltcnn.patch]
 """
@@ -25,7 +26,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "CMakeLists.txt", "source/Lib/EncoderLib/CMakeLists.txt"]
+FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "CMakeLists.txt", "source/Lib/EncoderLib/CMakeLists.txt",
+         "source/Lib/EncoderLib/EncSlice.cpp"]
 
 
 def replace_once(text, old, new, what):
@@ -108,7 +110,12 @@ def patch_lib_cmake(t):
                "set_property(TARGET EncoderLib PROPERTY CXX_STANDARD 14)\n", "EncoderLib CMake")
 
 
-PATCHERS = {FILES[0]: patch_enccu_cpp, FILES[1]: patch_enccu_h, FILES[2]: patch_top_cmake, FILES[3]: patch_lib_cmake}
+def patch_encslice_cpp(t):
+    # four OpenCV headers are included here but nothing of OpenCV is used in the file (found by LINKING the patched tree, round 3)
+    return cut(t, "#include <opencv2/opencv.hpp>", "#include <opencv2/highgui.hpp>", "", "EncSlice.cpp OpenCV includes")
+
+
+PATCHERS = {FILES[0]: patch_enccu_cpp, FILES[1]: patch_enccu_h, FILES[2]: patch_top_cmake, FILES[3]: patch_lib_cmake, FILES[4]: patch_encslice_cpp}
 
 
 def main():
