@@ -5,6 +5,12 @@
 
 #define MLT_MAX_HEADS_K 4
 #define MLT_MAX_LOGITS_K 16
+// Flat-content guard statistic (round 3: widened from "exactly constant"): an aligned 4-pixel quad counts when the RANGE (max - min)
+// of its four org values AND of its four |org - pred| values -- as the network sees them: uint16 cast, absdiff, clip to 10 bits --
+// is <= MLT_FLAT_RANGE.  0 restores the exactly-constant test.  8 covers +-1 LSB dither, low-contrast texture (amplitude <= 4),
+// ramps up to 2.67 luma steps per pixel and every exactly-constant area (sky, letterbox bars, screen content): content on which
+// neighbouring pixels carry correlated fp16 rounding errors that the global pooling cannot average away.
+#define MLT_FLAT_RANGE 8
 
 struct ConvArgs {
   const void *x;      // input  [n][Hin][Hin][CIN]  fp16 NHWC
@@ -67,7 +73,7 @@ struct StemBlockArgs {
   const void *w2;              // layer0.0.conv2 packed weights (18 KiB)
   const float *bias, *bias_sc, *bias2;
   void *y;                     // b0 [n][H][H][32] fp16
-  int32_t *flat;               // NULL, or [n] zero-initialised: += number of exactly-constant 4-pixel quads of each CU
+  int32_t *flat;               // NULL, or [n] zero-initialised: += number of near-constant (MLT_FLAT_RANGE) 4-pixel quads of each CU
                                // (flat-content guard; same statistic as flat_stat_kernel)
   float acc_scale;             // composed-weight storage scale (2^-12)
   int n, hout_l, ntiles;       // H = 1 << hout_l (>= 32), picture 2H x 2H; tiles of 16 x 32 output pixels
@@ -127,7 +133,7 @@ struct HeadArgs {
 struct FlatStatArgs {
   const int16_t *org, *pred;   // Pel planes
   long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements
-  int32_t *flat;               // [n] number of 4-pixel quads whose (org, |org-pred|) pairs are all identical
+  int32_t *flat;               // [n] number of near-constant 4-pixel quads (MLT_FLAT_RANGE)
   int n, s_l;                  // CU size S = 1 << s_l
 };
 struct GuardSelectArgs {

@@ -145,6 +145,16 @@ __device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
 }
 
 
+// Flat-content guard statistic of one aligned quad (mlt_kernels.h: MLT_FLAT_RANGE): w[j] = prep_pair() of its four pixels, i.e. exact
+// integers <= 1023 as fp16 pairs (org, |org - pred|) -> packed min / max / subtract are exact.
+__device__ __forceinline__ bool quad_near_flat(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  const half2v a = *(half2v *)&w0, b = *(half2v *)&w1, c = *(half2v *)&w2, d = *(half2v *)&w3;
+  const half2v mx = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+  const half2v mn = __builtin_elementwise_min(__builtin_elementwise_min(a, b), __builtin_elementwise_min(c, d));
+  const half2v r = mx - mn;
+  return r[0] <= (_Float16)MLT_FLAT_RANGE && r[1] <= (_Float16)MLT_FLAT_RANGE;
+}
+
 // ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------
 // After a 32x32 MFMA lane l = (p, h) holds, per register quad q, output channels 8q+4h .. 8q+4h+3 of pixel p, so
 // lanes p and p+32 own the two 8-byte halves of one 16-byte span.  v_permlane32_swap exchanges the upper half-wave
@@ -2513,7 +2523,7 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
     }
   };
   auto commit_raw = [&](int n) {
-    int nflat = 0;  // wave-uniform: own quads whose four (org, |org - pred|) pairs are identical (flat_stat_kernel's statistic)
+    int nflat = 0;  // wave-uniform: own quads that are near-constant in both planes the network sees (flat_stat_kernel's statistic)
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const bool item = rdst[u] >= 0;
@@ -2525,7 +2535,7 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
         const int16_t o = (int16_t)(vo[u][j >> 1] >> (16 * (j & 1))), q = (int16_t)(vp[u][j >> 1] >> (16 * (j & 1)));
         w[j] = zf ? 0u : prep_pair(o, q);
       }
-      if (a.flat) nflat += __builtin_popcountll(__ballot(item && (rdst[u] & (1 << 29)) && w[1] == w[0] && w[2] == w[0] && w[3] == w[0]));
+      if (a.flat) nflat += __builtin_popcountll(__ballot(item && (rdst[u] & (1 << 29)) && quad_near_flat(w[0], w[1], w[2], w[3])));
       if (!item) continue;
       uint2v ev, od;  // parity-split columns: pixels 0, 2 -> even half, 1, 3 -> odd half (8-byte stores)
       ev[0] = w[0]; ev[1] = w[2]; od[0] = w[1]; od[1] = w[3];
@@ -2726,8 +2736,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Parity guard of the fast arithmetic.  fp16 rounding noise is averaged away by the global pooling only where
 // neighbouring pixels DIFFER: on exactly-constant areas every pixel carries the same rounding error (measured: a constant
-// 128x128 CU reaches |dlogit| 1.3e-3, ordinary content 2-7e-4).  flat_stat_kernel counts, per CU, the aligned 4-pixel
-// quads whose (org, |org - pred|) pairs are all identical; guard_select_kernel lists the CUs whose count reaches the
+// 128x128 CU reaches |dlogit| 1.3e-3, ordinary content 2-7e-4), and nearly so where they differ by a few LSB (dither, low
+// contrast, gentle ramps: rms 1.2-1.5x the textured one, measured per content class in round 3).  flat_stat_kernel counts,
+// per CU, the aligned 4-pixel quads whose org values and whose |org - pred| values each span <= MLT_FLAT_RANGE; guard_select_kernel lists the CUs whose count reaches the
 // threshold (and, optionally, those whose decision-head margin is small); the host runtime re-evaluates exactly those
 // CUs with the exact (hi, lo) arithmetic (gather -> exact network -> scatter).  Integer statistics: deterministic.
 // ---------------------------------------------------------------------------------------------
@@ -2750,9 +2761,8 @@ __global__ __launch_bounds__(256) void flat_stat_kernel(const FlatStatArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { vo[j] = o[(size_t)y * a.org_row_stride + x + j]; vp[j] = p[(size_t)y * a.pred_row_stride + x + j]; }
     }
-    const uint32_t w0 = prep_pair(vo[0], vp[0]);  // what the network sees (uint16 cast, absdiff, clip)
-    const bool flat = prep_pair(vo[1], vp[1]) == w0 && prep_pair(vo[2], vp[2]) == w0 && prep_pair(vo[3], vp[3]) == w0;
-    cnt += flat ? 1 : 0;
+    // what the network sees (uint16 cast, absdiff, clip)
+    cnt += quad_near_flat(prep_pair(vo[0], vp[0]), prep_pair(vo[1], vp[1]), prep_pair(vo[2], vp[2]), prep_pair(vo[3], vp[3])) ? 1 : 0;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);

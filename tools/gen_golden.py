@@ -86,6 +86,22 @@ CASES = [
     ("uniform_w23", 23, "plain", 1012, synth.KIND_UNIFORM, 3, None),
     ("zero_resi_w24", 24, "plain", 1013, synth.KIND_ZERO_RESI, 2, None),
     ("out_of_range_pels", 25, "plain", 1014, synth.KIND_OUT_OF_RANGE, 3, None),
+    # round 3: content the flat-content guard used not to see -- near-threshold partial-flat, one plane flat,
+    # ramps, +-1 LSB dither, low contrast, zero residual on flat org -- on the bench weight set and on a second one
+    ("partial_flat", 10, "plain", 1020, synth.KIND_PARTIAL_FLAT, 3, None),
+    ("org_flat_pred_tex", 10, "plain", 1021, synth.KIND_ORG_FLAT_PRED_TEX, 3, None),
+    ("org_tex_pred_flat", 10, "plain", 1022, synth.KIND_ORG_TEX_PRED_FLAT, 3, None),
+    ("ramp", 10, "plain", 1023, synth.KIND_RAMP, 4, None),
+    ("dither", 10, "plain", 1024, synth.KIND_DITHER, 3, None),
+    ("low_contrast", 10, "plain", 1025, synth.KIND_LOW_CONTRAST, 3, None),
+    ("flat_zero_resi", 10, "plain", 1026, synth.KIND_FLAT_ZERO_RESI, 2, None),
+    ("partial_flat_w21", 21, "plain", 1030, synth.KIND_PARTIAL_FLAT, 3, None),
+    ("org_flat_pred_tex_w21", 21, "plain", 1031, synth.KIND_ORG_FLAT_PRED_TEX, 3, None),
+    ("org_tex_pred_flat_w21", 21, "plain", 1032, synth.KIND_ORG_TEX_PRED_FLAT, 3, None),
+    ("ramp_w21", 21, "plain", 1033, synth.KIND_RAMP, 4, None),
+    ("dither_w21", 21, "plain", 1034, synth.KIND_DITHER, 3, None),
+    ("low_contrast_w21", 21, "plain", 1035, synth.KIND_LOW_CONTRAST, 3, None),
+    ("dither_w11", 11, "plain", 1036, synth.KIND_DITHER, 3, None),
 ]
 
 
