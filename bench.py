@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (C oracle over the whole batch = full-batch parity, torch port)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CUs of the batch the C oracle evaluates (default: whole batch when the host has >= 64 cores)")
+    ap.add_argument("--weight-seed", type=int, default=10, help="seed of the synthetic weight set (10 = the BASELINE workload; 13 / 24 land in the hi+lo-weights tier)")
     ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags (1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16)")
     ap.add_argument("--latency", action="store_true", help="also time the synchronous one-CU-per-call path (mlt_predict)")
     ap.add_argument("--host-staged", action="store_true",
@@ -103,7 +104,9 @@ def main():
         sys.exit(2)
     dist = None
     rccl = None
-    if world > 1:
+    # under a torchrun launch (RANK / WORLD_SIZE in the environment) the process group is initialised even for ONE rank, so that a
+    # 1-GPU box exercises the RCCL path end to end (communicator set-up + weight-blob broadcast on device tensors)
+    if world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -134,8 +137,8 @@ def main():
     size, B = args.size, args.batch
     arch = pkg.synth.arch_for_size(size)
     # ---- weights: rank 0 builds the blob, everyone else receives it over RCCL (xGMI) ----
-    blob = pkg.weights.synthetic_blob(arch, 10) if rank == 0 else None
-    if world > 1:
+    blob = pkg.weights.synthetic_blob(arch, args.weight_seed) if rank == 0 else None
+    if dist is not None:
         pkg.shard.broadcast_blob(blob, dist, cdev)  # first collective also sets up the communicator: time the second
         torch.cuda.synchronize()
         dist.barrier()
@@ -181,10 +184,16 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        own = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allt, own)  # every rank's own time: a straggler GPU is visible in the line
+        te = own.clone()
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+        rates = [B * args.steps / float(x.item()) for x in allt]
+        per_rank = {"cu_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1)}
     # ---- the same steps again with HIP events around every kernel launch (on the launch stream): per-kernel table ----
     m.profile_enable(True)
     for _ in range(args.steps):
@@ -248,23 +257,32 @@ def main():
                         "algo_gbs": round(r["bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1),
                         "bound": "mfma" if by > 0 and fl / by >= ridge else "hbm",
                         "roof_frac": round(kb_ms / max(avg_ms, 1e-9), 4)})
+    # HBM traffic per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/make_traffic_json.py); only valid
+    # for the sources it was measured on: otherwise null.  Every kernel row carries it next to its algorithmic bytes.
+    tj, traffic_valid, traffic_meta = {}, False, {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic_meta = tj.get("_meta", {})
+        traffic_valid = traffic_meta.get("source_sig") == source_signature()
+    for k, r in zip(kernels, prof):
+        t = tj.get(f"{r['name']}@{B}") if traffic_valid else None
+        by = r["bytes"] / max(r["launches"], 1)
+        k["algo_bytes_per_launch"] = by
+        k["traffic"] = t["hbm_bytes_per_launch"] if t else None
+        k["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / by, 3) if t and by > 0 else None
     roofline = None
     dom = min(prof, key=lambda r: (-r["flops"], r["name"])) if prof else None
     if dom:
         avg_ms = dom["total_ms"] / dom["launches"]
         flops_l, bytes_l = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
         mfma_bound = bytes_l > 0 and flops_l / bytes_l >= ridge
-        # HBM traffic per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/make_traffic_json.py);
-        # only valid for the sources it was measured on: otherwise null
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            meta = tj.get("_meta", {})
+        if tj:
             t = tj.get(f"{dom['name']}@{B}")
-            if t and meta.get("source_sig") == source_signature():
+            if t and traffic_valid:
                 traffic = t["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/pmc_traffic.json ({meta.get('tag')}, sources {meta.get('source_sig')})"
+                traffic_src = f"profiles/pmc_traffic.json ({traffic_meta.get('tag')}, sources {traffic_meta.get('source_sig')})"
             else:
                 traffic_src = "null: profiles/pmc_traffic.json was measured on different kernel sources" if t else "null: kernel not in profiles/pmc_traffic.json"
         if mfma_bound:
@@ -297,38 +315,37 @@ def main():
                  "sample": f"first {sample} CUs of the same batch, one pass, {cs:.1f} s"}
         cpu_baseline = {"value": c_row["value"], "unit": "CU-inferences/s", "cores": cores, "kind": "port", "sample": c_row["sample"],
                         "rows": [c_row]}
-        if size == 128 or True:
-            try:
-                tb = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--size", str(size), "--json"],
-                                    capture_output=True, text=True, timeout=600)
-                tl = [l for l in tb.stdout.splitlines() if l.startswith("{")]
-                if tb.returncode == 0 and tl:
-                    tj = json.loads(tl[-1])
-                    cpu_baseline["rows"] = tj["rows"] + [c_row]
-                    cpu_baseline.update({"value": tj["value"], "cores": tj["cores"], "sample": tj["sample"], "cpu_model": tj["cpu_model"],
-                                         "physical_cores": tj["physical_cores"], "logical_cpus": tj["logical_cpus"]})
-                else:
-                    cpu_baseline["torch_port_error"] = (tb.stderr or tb.stdout)[-400:]
-            except subprocess.TimeoutExpired:
-                cpu_baseline["torch_port_error"] = "timeout"
+        try:
+            tb = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--size", str(size), "--json"],
+                                capture_output=True, text=True, timeout=600)
+            tl = [l for l in tb.stdout.splitlines() if l.startswith("{")]
+            if tb.returncode == 0 and tl:
+                cj = json.loads(tl[-1])
+                cpu_baseline["rows"] = cj["rows"] + [c_row]
+                cpu_baseline.update({"cpu_model": cj["cpu_model"], "physical_cores": cj["physical_cores"], "logical_cpus": cj["logical_cpus"]})
+                if cj["value"] >= c_row["value"]:  # `value` = the best CPU row, C oracle included
+                    cpu_baseline.update({"value": cj["value"], "cores": cj["cores"], "sample": cj["sample"]})
+            else:
+                cpu_baseline["torch_port_error"] = (tb.stderr or tb.stdout)[-400:]
+        except subprocess.TimeoutExpired:
+            cpu_baseline["torch_port_error"] = "timeout"
     else:
         sample = min(B, 8 if args.no_cpu_baseline else 64)
         ref, ref_split = oracle.Oracle(blob).forward(org[:sample], pred[:sample], poc[:sample], qp[:sample], threads=min(cores, sample))
-    if True:
-        hs, lo = [], 0
-        for c in pkg.synth.HEAD_CLASSES[arch]:
-            hs.append(slice(lo, lo + c))
-            lo += c
-        dec = hs[2 if size == 128 else 0]
-        srt = np.sort(ref[:, dec].astype(np.float64), axis=1)
-        decisive = (srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL  # the reference's own top-2 margin exceeds the tolerance band
-        mism = got_split[:sample] != ref_split
-        parity = {"checked_cus": int(sample), "of_batch": int(B), "max_abs_dlogit": float(np.abs(got_logits[:sample] - ref).max()),
-                  "tolerance": LOGIT_TOL, "within_tolerance": bool(np.abs(got_logits[:sample] - ref).max() <= LOGIT_TOL),
-                  "split_mismatch_decisive": int((mism & decisive).sum()), "non_decisive": int((~decisive).sum()),
-                  "split_mismatch_non_decisive": int((mism & ~decisive).sum()),
-                  "split_identical": bool(not (mism & decisive).any()),
-                  "oracle": "oracle/mlt_oracle.c (fp32 restatement pinned to the reference fixtures)"}
+    hs, lo = [], 0
+    for c in pkg.synth.HEAD_CLASSES[arch]:
+        hs.append(slice(lo, lo + c))
+        lo += c
+    dec = hs[2 if size == 128 else 0]
+    srt = np.sort(ref[:, dec].astype(np.float64), axis=1)
+    decisive = (srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL  # the reference's own top-2 margin exceeds the tolerance band
+    mism = got_split[:sample] != ref_split
+    parity = {"checked_cus": int(sample), "of_batch": int(B), "max_abs_dlogit": float(np.abs(got_logits[:sample] - ref).max()),
+              "tolerance": LOGIT_TOL, "within_tolerance": bool(np.abs(got_logits[:sample] - ref).max() <= LOGIT_TOL),
+              "split_mismatch_decisive": int((mism & decisive).sum()), "non_decisive": int((~decisive).sum()),
+              "split_mismatch_non_decisive": int((mism & ~decisive).sum()),
+              "split_identical_decisive": bool(not (mism & decisive).any()), "split_identical": bool(not mism.any()),
+              "oracle": "oracle/mlt_oracle.c (fp32 restatement pinned to the reference fixtures)"}
 
     tier = int(arith["exact"])  # 0 fast, 1 exact, 2 hi+lo weights on fp16 activations (the tier a weight set that fails the fast calibration tries first)
     exact = tier == 1
@@ -340,15 +357,16 @@ def main():
         "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else "f16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if size == 128 else 2}]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
-                   "batch_per_gpu": B, "cu_size": size, "weights": "synthetic seed 10 (no trained checkpoint is distributed)",
+                   "batch_per_gpu": B, "cu_size": size, "weights": f"synthetic seed {args.weight_seed} (no trained checkpoint is distributed)",
                    "parallelism": f"shard{world}",
-                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else "fast (single fp16 pass)") + " + flat-content guard" + (" + decision guard" if arith["decision_guard"] else ""),
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
                                   "guard_reruns_total": arith["guard_reruns"]}},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,
         "rccl": rccl,
+        "per_rank": per_rank,
         "derived": {"model_tflops": round(value * FLOP_PER_CU[size] / 1e12, 1),
                     "mfma_frac_whole_net": round(value / world * FLOP_PER_CU[size] / 1e12 / MFMA_PEAK_TFLOPS, 4),
                     "hbm_layerwise_roofline_frac": round(value / world * LAYERWISE_BYTES_PER_CU[size] / 1e9 / HBM_PEAK_GBS, 4),
@@ -363,7 +381,7 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    if parity is not None and not (parity["within_tolerance"] and parity["split_identical"]):
+    if parity is not None and not (parity["within_tolerance"] and parity["split_identical_decisive"]):
         print("bench.py: PARITY FAILURE " + json.dumps(parity), file=sys.stderr)
         sys.exit(3)
 

@@ -102,21 +102,31 @@ def main():
     size = args.size
     blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 10)
     rows = []
-    # ---- one process, threads = physical cores: batch 1 (encoder-realistic) and batch 64 ----
-    torch.set_num_threads(physical)
+    # ---- one process: batch 1 (the encoder's call pattern, EncCu.cpp:894-909) and batch 64.  The thread count is SWEPT: one
+    # 128x128 CU on all 128 cores of the GPU box is an oversubscription lottery (round 2: 5 CU/s in the driver's run, 160 in ours);
+    # every T is reported and the best one is the row that counts ----
     port = TorchPort(blob)
     org, pred = pkg.synth.make_patches_bulk(size, 64, 0xC0FFEE)
     poc, qp = pkg.synth.make_scalars(64, 0xC0FFEE)
+    sweep_T = sorted({t for t in (8, 16, 32, 64, 128) if t <= physical} | {physical})
     for b in (1, 64):
-        ts = []
-        for i in range(args.warmup + (args.runs if b == 1 else max(args.runs // 2, 3))):
-            t0 = time.perf_counter()
-            port.forward(org[:b], pred[:b], poc[:b], qp[:b], chunk=64)
-            if i >= args.warmup:
-                ts.append(time.perf_counter() - t0)
-        med = statistics.median(ts)
-        rows.append({"impl": "torch-CPU port (oracle/torch_port.py, oneDNN fp32)", "batch": b, "procs": 1, "threads": physical,
-                     "value": round(b / med, 2), "median_s": round(med, 5), "runs": len(ts), "warmup": args.warmup})
+        best_row, sweep = None, {}
+        for T in sweep_T:
+            torch.set_num_threads(T)
+            ts = []
+            for i in range(args.warmup + (args.runs if b == 1 else max(args.runs // 2, 3))):
+                t0 = time.perf_counter()
+                port.forward(org[:b], pred[:b], poc[:b], qp[:b], chunk=64)
+                if i >= args.warmup:
+                    ts.append(time.perf_counter() - t0)
+            med = statistics.median(ts)
+            sweep[str(T)] = round(b / med, 2)
+            row = {"impl": "torch-CPU port (oracle/torch_port.py, oneDNN fp32)", "batch": b, "procs": 1, "threads": T,
+                   "value": round(b / med, 2), "median_s": round(med, 5), "runs": len(ts), "warmup": args.warmup}
+            if best_row is None or row["value"] > best_row["value"]:
+                best_row = row
+        best_row["thread_sweep_cu_per_s"] = sweep
+        rows.append(best_row)
     # ---- the batch workload sharded over P processes x T threads ----
     T = args.threads or 1
     P = args.procs or max(physical // T, 1)

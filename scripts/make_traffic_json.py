@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate runs).
+"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/prof_run.py (separate runs).
 HBM bytes per launch = 2 * FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)
-+ WRITE_SIZE, both in KiB.  usage: make_traffic_json.py <fetch_csv> <write_csv> <batch> <out.json>"""
++ WRITE_SIZE, both in KiB.
+
+Only the LAST `steps` dispatches of every kernel name are averaged: the load-time calibration launches the same kernels on
+16-CU sub-batches before the timed batches, and averaging over all dispatches of a name diluted the figures of every kernel
+that also runs there (round 2: stem_block / block32 / 32->64 / chain<64> were reported at 2/3 of their real traffic).  The
+dispatch count that went into each average is recorded and the averaged dispatches must agree within 5 %.
+
+usage: make_traffic_json.py <fetch_csv> <write_csv> <batch> <out.json> <tag> <source_sig> [steps = 2]"""
 import collections
 import csv
 import json
@@ -11,9 +18,10 @@ import sys
 H_BY_COUT = {32: 64, 64: 32, 128: 16, 256: 8}
 
 
-def per_kernel(path, counter):
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
+def per_kernel(path, counter, steps):
+    acc = collections.defaultdict(list)
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+    for r in rows:
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
@@ -39,21 +47,33 @@ def per_kernel(path, counter):
             name = "heads"
         else:
             continue
-        acc[name][0] += float(r["Counter_Value"])
-        acc[name][1] += 1
-    return {k: v[0] / v[1] for k, v in acc.items()}
+        acc[name].append(float(r["Counter_Value"]))
+    out = {}
+    for k, v in acc.items():
+        last = v[-steps:]  # the batch launches come last (calibration / warm-up dispatches of the same kernel precede them)
+        mean = sum(last) / len(last)
+        spread = (max(last) - min(last)) / mean if mean > 0 else 0.0
+        out[k] = {"mean": mean, "n": len(last), "of": len(v), "spread": spread}
+    return out
 
 
 def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     tag, sig = (sys.argv[5], sys.argv[6]) if len(sys.argv) > 6 else ("?", "?")
-    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    steps = int(sys.argv[7]) if len(sys.argv) > 7 else 2
+    f, w = per_kernel(fetch, "FETCH_SIZE", steps), per_kernel(write, "WRITE_SIZE", steps)
     # _meta.source_sig: bench.py only quotes these figures while the kernel / runtime sources still hash to it
     res = {"_meta": {"tag": tag, "source_sig": sig, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 scripts/prof_run.py 4096 2"}}
     for name in f:
-        res[f"{name}@{batch}"] = {"batch": batch, "fetch_kib_raw": f[name], "write_kib": w.get(name, 0.0),
-                                  "hbm_bytes_per_launch": (2.0 * f[name] + w.get(name, 0.0)) * 1024.0,
-                                  "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts wide reads at half)"}
+        wv = w.get(name, {"mean": 0.0, "n": 0, "of": 0, "spread": 0.0})
+        assert f[name]["n"] == steps or f[name]["of"] < steps, (name, f[name])
+        res[f"{name}@{batch}"] = {"batch": batch, "fetch_kib_raw": f[name]["mean"], "write_kib": wv["mean"],
+                                  "hbm_bytes_per_launch": (2.0 * f[name]["mean"] + wv["mean"]) * 1024.0,
+                                  "dispatches_averaged": f[name]["n"], "dispatches_of_this_name": f[name]["of"],
+                                  "spread_fetch": round(f[name]["spread"], 4), "spread_write": round(wv["spread"], 4),
+                                  "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts wide reads at half); last `dispatches_averaged` dispatches only"}
+        if f[name]["n"] == steps and max(f[name]["spread"], wv["spread"]) > 0.05:
+            res[f"{name}@{batch}"]["warning"] = "averaged dispatches differ by more than 5 %: not all of them are batch launches"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -752,3 +752,81 @@ def test_bench_contract_two_ranks_on_one_gpu(gpu):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert d["per_rank"] and len(d["per_rank"]["cu_per_s"]) == 2 and d["per_rank"]["min"] <= d["per_rank"]["max"]   # a straggler rank would show
+
+
+def test_rccl_single_rank_weight_broadcast_and_bench_line(gpu, tmp_path):
+    """What a 1-GPU box can prove of the multi-GPU path (north_star "RCCL broadcast of weights over xGMI"): RCCL itself
+    (torch.distributed backend "nccl") initialises, shard.broadcast_blob moves the weight blob through DEVICE tensors and returns
+    it unchanged, and bench.py launched the way the driver launches it (torch.distributed.run, one rank) reports rccl.backend ==
+    "nccl" with parity-clean results.  Both in child processes: a process group is process-global state."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29000 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MLT_BENCH_OVERSUBSCRIBE"):
+        env.pop(k, None)
+    probe = tmp_path / "rccl_probe.py"
+    probe.write_text(f"""
+import hashlib, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+import mltcnn_pkg
+pkg = mltcnn_pkg.load()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+blob = pkg.weights.synthetic_blob(0, 10)
+got = pkg.shard.broadcast_blob(blob, dist, torch.device("cuda", 0))
+assert got == blob, "blob changed on its way through RCCL"
+t = torch.arange(8, dtype=torch.int32, device="cuda")
+dist.all_reduce(t)
+assert t.cpu().tolist() == list(range(8))
+dist.destroy_process_group()
+print("RCCL_OK", hashlib.sha256(got).hexdigest()[:16], len(got))
+""")
+    out = subprocess.run([sys.executable, str(probe)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port + 1),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["world"] == 1 and d["rccl"]["weight_blob_bytes"] > 1e6
+    assert d["parity"]["max_abs_dlogit"] <= LOGIT_TOL and d["parity"]["split_mismatch_decisive"] == 0
+    assert d["per_rank"]["cu_per_s"] and abs(d["per_rank"]["max"] - d["value"]) / d["value"] < 0.05
+
+
+def test_contexts_on_every_device_of_one_process(gpu):
+    """The encoder's natural multi-GPU mode is ONE process with a context per device (mlt_config.device): mlt_init on every ordinal
+    hipGetDeviceCount() reports (+ a second context on ordinal 0), batches interleaved across the contexts, every context returns the
+    same bits.  Runs with one device too (two contexts on it)."""
+    import torch
+    pkg = gpu
+    size, n = 128, 24
+    blob = pkg.weights.synthetic_blob(0, 10)
+    org, pred = pkg.synth.make_patches(size, n, 31)
+    poc, qp = pkg.synth.make_scalars(n, 31)
+    ndev = torch.cuda.device_count()
+    ctxs = [pkg.MltCnn(device=d, sizes=(size,), blobs={size: blob}) for d in list(range(ndev)) + [0]]
+    assert len(ctxs) >= 2
+    res = [None] * len(ctxs)
+    for lo, hi in ((0, 7), (7, 8), (8, 24)):          # interleaved: every context sees each slice before anyone sees the next
+        for i, c in enumerate(ctxs):
+            s, l = c.predict_batch(org[lo:hi], pred[lo:hi], poc[lo:hi], qp[lo:hi])
+            res[i] = (s, l) if res[i] is None else (np.concatenate([res[i][0], s]), np.concatenate([res[i][1], l]))
+    for i in range(1, len(ctxs)):
+        assert np.array_equal(res[i][0], res[0][0]) and np.array_equal(res[i][1], res[0][1]), f"context {i} differs"
+    s1, l1 = ctxs[-1].predict(org[3], pred[3], int(poc[3]), int(qp[3]))
+    assert s1 == res[0][0][3] and np.array_equal(l1, res[0][1][3])
+    try:
+        pkg.MltCnn(device=ndev, sizes=(size,), blobs={size: blob})     # one past the last ordinal: fails loudly, no fallback to device 0
+        raise AssertionError("mlt_init accepted a device ordinal that does not exist")
+    except pkg.capi.MltError as e:
+        assert e.code == pkg.capi.MLT_ERR_NO_DEVICE, e
+    for c in ctxs:
+        c.close()
