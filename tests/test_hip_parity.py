@@ -827,6 +827,6 @@ def test_contexts_on_every_device_of_one_process(gpu):
         pkg.MltCnn(device=ndev, sizes=(size,), blobs={size: blob})     # one past the last ordinal: fails loudly, no fallback to device 0
         raise AssertionError("mlt_init accepted a device ordinal that does not exist")
     except pkg.capi.MltError as e:
-        assert e.code == pkg.capi.MLT_ERR_NO_DEVICE, e
+        assert e.code == 2, e   # MLT_ERR_NO_DEVICE (include/mltcnn.h)
     for c in ctxs:
         c.close()
