@@ -152,6 +152,7 @@ int upload_model(mlt_ctx *ctx, mlt::Model &m) {
   };
   int rc;
   if ((rc = up(m.stem))) return rc;
+  if ((rc = up(m.stem_b))) return rc;
   for (int s = 0; s < m.n_stages; ++s)
     for (int b = 0; b < 2; ++b) {
       if ((rc = up(m.blocks[s][b].conv1))) return rc;
@@ -177,6 +178,7 @@ void free_model(mlt::Model &m) {
     pc.d_w = nullptr; pc.d_bias = pc.d_bias_sc = nullptr;
   };
   fr(m.stem);
+  fr(m.stem_b);
   for (int s = 0; s < 5; ++s)
     for (int b = 0; b < 2; ++b) { fr(m.blocks[s][b].conv1); fr(m.blocks[s][b].conv2); fr(m.blocks[s][b].conv1_s2c); }
   for (int h = 0; h < 4; ++h) { if (m.heads[h].d_w) (void)hipFree(m.heads[h].d_w); if (m.heads[h].d_b) (void)hipFree(m.heads[h].d_b); m.heads[h].d_w = m.heads[h].d_b = nullptr; }
@@ -363,11 +365,11 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   const mlt::PackedConv &c2 = m.blocks[0][0].conv2;
   StemBlockArgs a{};
   a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
-  a.w = m.stem.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
+  a.w = m.stem_b.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
   a.flat = d_flat;
   if (d_flat) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
-  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "stem+block_s2_2to32_h%d(layer0.0)", h);
@@ -738,15 +740,15 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
 }
 
 // ---- load-time calibration of the fast arithmetic against the exact one (include/mltcnn.h: mlt_load_weights) ----
-// Calibration set (round 3): NOT only the bench's texture distribution.  64 seeded CUs in six content classes -- every class the
+// Calibration set (round 3): NOT only the bench's texture distribution.  96 seeded CUs in five content classes -- the classes the
 // flat-content guard does NOT re-evaluate exactly, because admission must be decided on what the fast arithmetic will really see:
-//   0 texture (blocky base + texture +-48, pred = org + noise +-40; 24 CUs)      1 i.i.d. uniform org and pred (large residuals; 8)
-//   2 constant org / textured pred (8)     3 textured org / constant pred (8)    4 texture with a constant band over 10-12 % of the
-//   quads, just under the guard's 1/8 (8)  5 steep luma ramps, 3-6 steps per pixel, pred = the ramp shifted by 1-2 pixels (8)
-// (content the guard catches -- constant, dithered, low-contrast, gentle ramps -- is evaluated with the exact arithmetic anyway).
-constexpr int kCalibClasses = 6;
-constexpr int kCalibCount[kCalibClasses] = {24, 8, 8, 8, 8, 8};
-constexpr int kCalibN = 64;
+//   0 texture (blocky base + texture +-48, pred = org + noise +-40; 32 CUs)      1 i.i.d. uniform org and pred (large residuals; 16)
+//   2 constant org / textured pred (16)    3 textured org / constant pred (16)   4 texture with a constant band over 10-12 % of the
+//   quads, just under the guard's 1/8 (16)
+// (content the guard catches -- constant, dithered, low-contrast, ramps -- is evaluated with the exact arithmetic anyway).
+constexpr int kCalibClasses = 5;
+constexpr int kCalibCount[kCalibClasses] = {32, 16, 16, 16, 16};
+constexpr int kCalibN = 96;
 
 void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t> &pred, std::vector<int32_t> &poc, std::vector<int32_t> &qp,
                           std::vector<int> &cls) {
@@ -764,7 +766,6 @@ void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t>
       std::vector<int> base((size_t)nb * nb);
       for (int &b : base) b = 64 + (int)(next() % 896);
       const int co = (int)(next() % 1024), cp = (int)(next() % 1024);
-      const int sx = 3 + (int)(next() % 4), sy = (k & 1) ? (int)(next() % 5) : 0, a0 = (int)(next() % 300), sh = 1 + (k & 1);
       int band_h = (S * (10 + k % 3)) / 100;
       if (band_h * 8 >= S) band_h = S / 8 - 1;
       if (band_h < 1) band_h = 1;
@@ -773,7 +774,6 @@ void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t>
         for (int x = 0; x < S; ++x) {
           int vo, vp;
           if (c == 1) { vo = (int)(next() % 1024); vp = (int)(next() % 1024); }
-          else if (c == 5) { vo = clip(a0 + sx * x + sy * y); vp = clip(a0 + sx * (x + sh) + sy * (y + sh)); }
           else {
             vo = clip(base[(size_t)(y / bs) * nb + x / bs] + (int)(next() % 97) - 48);
             vp = clip(vo + (int)(next() % 81) - 40);
@@ -855,6 +855,13 @@ int calibrate(mlt_ctx *ctx, SizeState &st, bool w2) {  // w2: price the middle t
   double worst = 0.0;
   for (int c = 0; c < kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
   for (int h = 0; h < st.model.n_heads; ++h) if (n_head[h]) { const double r = std::sqrt(s2_head[h] / (double)n_head[h]); if (!(r <= worst)) worst = r; }
+  if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
+    std::fprintf(stderr, "mltcnn calibration (size %d, %s): rms per class", S, w2 ? "hi+lo weights" : "single pass");
+    for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
+    std::fprintf(stderr, " | per head");
+    for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
+    std::fprintf(stderr, " | max %.3e\n", mx);
+  }
   st.calibrated = true;
   st.calib_rms = (float)worst;
   st.calib_max = (float)mx;

@@ -7,9 +7,9 @@
 #define MLT_MAX_LOGITS_K 16
 // Flat-content guard statistic (round 3: widened from "exactly constant"): an aligned 4-pixel quad counts when the RANGE (max - min)
 // of its four org values AND of its four |org - pred| values -- as the network sees them: uint16 cast, absdiff, clip to 10 bits --
-// is <= MLT_FLAT_RANGE.  0 restores the exactly-constant test.  8 covers +-1 LSB dither, low-contrast texture (amplitude <= 4),
-// ramps up to 2.67 luma steps per pixel and every exactly-constant area (sky, letterbox bars, screen content): content on which
-// neighbouring pixels carry correlated fp16 rounding errors that the global pooling cannot average away.
+// is <= MLT_FLAT_RANGE -- +-1 LSB dither, low-contrast texture (amplitude <= 4), every exactly-constant area (sky, letterbox bars,
+// screen content) -- or the four values are LINEAR to within one step (ramps of any slope); per plane either test may hold.  Content
+// on which neighbouring pixels carry correlated fp16 rounding errors that the global pooling cannot average away.
 #define MLT_FLAT_RANGE 8
 
 struct ConvArgs {

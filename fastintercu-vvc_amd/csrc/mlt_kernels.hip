@@ -146,13 +146,19 @@ __device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
 
 
 // Flat-content guard statistic of one aligned quad (mlt_kernels.h: MLT_FLAT_RANGE): w[j] = prep_pair() of its four pixels, i.e. exact
-// integers <= 1023 as fp16 pairs (org, |org - pred|) -> packed min / max / subtract are exact.
+// integers <= 1023 as fp16 pairs (org, |org - pred|) -> packed min / max / add / subtract are exact (|values| <= 2046).  A plane of the
+// quad is "coherent" when its four values span <= MLT_FLAT_RANGE (constant, dither, low contrast) OR are linear to within one step
+// (both second differences <= 1 in magnitude: ramps of any slope -- every pixel of a perfect gradient sees the same local pattern,
+// so its rounding errors are as coherent as a constant area's); the quad counts when BOTH planes are.
 __device__ __forceinline__ bool quad_near_flat(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
   const half2v a = *(half2v *)&w0, b = *(half2v *)&w1, c = *(half2v *)&w2, d = *(half2v *)&w3;
   const half2v mx = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
   const half2v mn = __builtin_elementwise_min(__builtin_elementwise_min(a, b), __builtin_elementwise_min(c, d));
   const half2v r = mx - mn;
-  return r[0] <= (_Float16)MLT_FLAT_RANGE && r[1] <= (_Float16)MLT_FLAT_RANGE;
+  const half2v d1 = (a + c) - (b + b), d2 = (b + d) - (c + c);
+  const half2v l = __builtin_elementwise_max(__builtin_elementwise_max(d1, -d1), __builtin_elementwise_max(d2, -d2));
+  const _Float16 R = (_Float16)MLT_FLAT_RANGE, one = (_Float16)1;
+  return (r[0] <= R || l[0] <= one) && (r[1] <= R || l[1] <= one);
 }
 
 // ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------
@@ -2437,7 +2443,7 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
 
 // ---------------------------------------------------------------------------------------------
 // Whole first BasicBlock (layer0.0) from the raw Pel planes, fast arithmetic, output maps >= 32 x 32:
-//     t  = relu(bn1(conv1(stem x)))         composed 5x5 stride-2 conv + border slots   (see stem5_kernel)
+//     t  = relu(bn1(conv1(stem x)))         composed 5x5 stride-2 conv + border k-steps   (see stem5_kernel)
 //     b0 = relu(bn2(conv2(t)) + bn(shortcut(stem x)))
 // One workgroup owns a 16 x 32 tile of b0: the raw (org, |org-pred|) patch for tile + 1-pixel halo of t is staged in LDS
 // (39 x 71 pixels, 11 KiB), t is evaluated on 18 x 34 pixels and kept in LDS as fp16 (zero outside the picture = conv2's
@@ -2445,65 +2451,70 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
 // rounded to fp16).  HBM sees 64 KiB of Pel planes in and 256 KiB of b0 out per 128x128 CU -- t and sc (2 x 256 KiB written
 // and read back by the two-kernel form) never exist.  conv2's weights are resident in LDS (and in registers during the
 // phase), the composed first-layer weights live in registers; persistent workgroups prefetch the next raw patch.
+// Round 3: the raw patch is ROW-MAJOR (one dword = the (org, resi) fp16 pair of a pixel, pitch 72 dwords) and the K order of the
+// composed weights (mlt_model.cpp: pack_stem_b) makes a lane's B fragment 16 contiguous bytes of it -- window row dy, columns
+// 2x-2+4h .. +3 -- so a 32-pixel block of t costs 5 ds_read2_b64 instead of 20-25 gathered ds_read_b32 (round 2: 22.8 % LDS bank
+// conflicts, MFMA busy 29 %); the three surplus columns of a row carry zero weights.  The border corrections (conv1 pads the STEM
+// map, the composed conv the INPUT: output row 0 / column 0 only) are two extra k-steps whose B operands are picked out of the
+// main fragments already in registers, executed only by blocks that contain such pixels.
 // ---------------------------------------------------------------------------------------------
-#ifndef CFG_STEMB_MINW
-#define CFG_STEMB_MINW 1
-#endif
-__global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const StemBlockArgs a) {
+// Round 3, second step: the kernel is a two-stage PIPELINE inside one workgroup.  Phase stamps of the serial form (commit -> barrier
+// -> phase 1 -> barrier -> phase 2 -> barrier, every wave doing everything) showed 10.8 k cycles per tile against an MFMA floor of
+// 3.4 k: phase 1 -- 5 MFMAs per 32-pixel block between an LDS round trip and a VALU epilogue -- is a latency chain that took as long
+// as phase 2 with its 8x more MFMAs, and commit + barriers another 30 %.  Now waves 0-3 run phase 1 of tile k while waves 4-7 run
+// phase 2 of tile k-1 (every SIMD hosts one wave of each kind: the latency-bound producer fills the issue slots the MFMA-dense
+// consumer leaves), every wave commits its share of the raw patch of tile k+1 at the top of the interval, and ONE barrier per tile
+// separates the intervals.  LDS: three raw buffers (tile k+1 being written, k read by phase 1, k-1 read by phase 2's shortcut), two T
+// buffers, conv2's weights (the consumer waves keep their 18 A fragments in registers), biases, border k-steps = 149 KiB.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) {
   constexpr int TH = 16, TW = 32, PS = 80;
   constexpr int T_H = TH + 2, T_W = TW + 2;                 // t region: tile + 1-pixel halo
   constexpr int RH = 2 * T_H + 3, RW = 2 * T_W + 3;         // raw patch 39 x 71
-  constexpr int HW = (RW + 1) / 2, RP = 2 * HW;             // parity-split columns, row pitch 72
-  constexpr int RAWBYTES = (RH * RP * 4 + 15) / 16 * 16, TBYTES = T_H * T_W * PS;
-  constexpr int NT = 512, NW = 8;
-  constexpr int QW = (RW + 3) / 4, UR = (RH * QW + NT - 1) / NT;  // raw rows are fetched as 18 quads of 4 pixels: 702 items, 2 per lane
+  constexpr int RP = 72;                                    // row pitch in dwords (pixels): quads of 4 pixels are 16-byte aligned
+  constexpr int RAWBYTES = RH * RP * 4 + 16, TBYTES = T_H * T_W * PS;  // (+16: the zero-weight columns of the last row's reads)
+  constexpr int NT = 512, NWS = 4;                          // waves per pipeline stage
+  constexpr int QW = RP / 4, UR = (RH * QW + NT - 1) / NT;  // raw rows are fetched as 18 quads of 4 pixels: 702 items, 2 per lane
+  static_assert(RW <= RP && RP % 4 == 0 && RAWBYTES % 16 == 0, "raw pitch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t *raw = (uint32_t *)smem;
-  char *T = smem + RAWBYTES, *W2 = T + TBYTES;
+  char *Tb = smem + 3 * RAWBYTES, *W2 = Tb + 2 * TBYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 31, h = lane >> 5;
   const int h_l = a.hout_l, H = 1 << h_l, S = 2 * H;        // output map H x H, picture S x S
   const int txs_l = h_l - 5, tys_l = h_l - 4;
   const int ntiles = a.ntiles;
-  auto tile_decode = [&](int t, int &tx, int &ty, int &n) {
+  if ((int)blockIdx.x >= ntiles) return;
+  const int nloc = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup
+  auto tile_decode = [&](int k, int &tx, int &ty, int &n) {
+    const int t = (int)blockIdx.x + k * (int)gridDim.x;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;  // XCD-contiguous tile order
     const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
     tx = mt & ((1 << txs_l) - 1);
     ty = (mt >> txs_l) & ((1 << tys_l) - 1);
     n = mt >> (txs_l + tys_l);
   };
-  for (int pi = wave; pi < 18; pi += NW) glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
-  // composed first-layer weights (5 k-steps for t, 2 for the shortcut) and all biases: registers, once per kernel
-  half8 am[5], as[2];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) am[k] = *(const half8 *)((const char *)a.w + k * 1024 + lane * 16);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) as[k] = *(const half8 *)((const char *)a.w + (5 + k) * 1024 + lane * 16);
-  // A first use inside the tile loop would make the compiler wait for these loads THERE, with s_waitcnt vmcnt(0) (it cannot
-  // count across the back edge) -- draining the next tile's raw-plane prefetch every iteration, i.e. exposing the HBM latency
-  // the prefetch exists to hide.  Using the registers here moves that wait in front of the loop.
-#pragma unroll
-  for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(am[k]));
-#pragma unroll
-  for (int k = 0; k < 2; ++k) asm volatile("" ::"v"(as[k]));
-  // biases in LDS (this kernel is register-bound: 48 VGPRs of biases meant spills inside the block loops):
-  // BL[0..31] = bias of conv1 (bn1), BL[32..63] = bias of conv2 (bn2) + bias of the shortcut, which are only ever added together
+  auto rawbuf = [&](int k) { return (uint32_t *)(smem + (k % 3) * RAWBYTES); };
+  for (int pi = wave; pi < 18; pi += 8) glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
+  // biases in LDS: BL[0..31] = bias of conv1 (bn1), BL[32..63] = bias of conv2 (bn2) + bias of the shortcut (only ever added together)
   float *BL = (float *)(W2 + 18 * 1024);
+  char *WB = (char *)(BL + 64);  // the two border k-steps' A fragments (2 KiB): read only by blocks that contain border pixels
+  if (wave < 2) glds16((const char *)a.w + (7 + wave) * 1024 + lane * 16, WB + wave * 1024);
   if (tid < 32) {
     BL[tid] = a.bias[tid];
     BL[32 + tid] = a.bias2[tid] + a.bias_sc[tid];
   }
+  if (tid < 12) ((uint32_t *)(smem + (tid >> 2) * RAWBYTES))[RH * RP + (tid & 3)] = 0u;
   // ---- raw patch: issue (global -> registers) / commit (registers -> LDS) ----
   // One item = 4 horizontally adjacent pixels of both planes (two 8-byte loads).  The patch starts at column 64*tx - 4 and the
   // planes are dense 2H x 2H int16 with 8-byte aligned rows (host guarantees it), so quads are aligned and lie entirely
   // inside or outside the picture.  (Pixel-wise 2-byte loads made ISSUING the next tile's loads 42 % of the tile time.)
   typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
   uint2v vo[UR], vp[UR];
-  int rdst[UR];  // dword index in `raw` of the quad's first even pixel, bit 30: zero-fill, -1: none
-  auto issue_raw = [&](int t) {
+  int rdst[UR];  // dword index in the raw buffer of the quad's first pixel, bit 30: zero-fill, bit 29: own quad (guard statistic), -1: none
+  auto issue_raw = [&](int k) {
     int tx, ty, n;
-    tile_decode(t, tx, ty, n);
+    tile_decode(k, tx, ty, n);
     const int iy0 = 2 * (ty * TH - 1) - 2, ix0 = 2 * (tx * TW - 1) - 2;
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
@@ -2515,21 +2526,31 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
       // bit 29: the quad lies in the part of the raw patch only THIS tile owns (rows / columns of its 32 x 64 input
       // pixels without the halo) -> counted once for the flat-content guard
       const bool own = in_items && ry >= 4 && ry < 4 + 2 * TH && qx >= 1 && qx <= 2 * TW / 4;
-      rdst[u] = in_items ? (ry * RP + 2 * qx) | (live ? 0 : 1 << 30) | (own ? 1 << 29 : 0) : -1;
+      rdst[u] = in_items ? (ry * RP + 4 * qx) | (live ? 0 : 1 << 30) | (own ? 1 << 29 : 0) : -1;
       const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + ((tid * 4) & (S - 1));
       const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + ((tid * 4) & (S - 1));
+#ifndef KO_SB_LOAD
       vo[u] = *(const uint2v *)(a.org + oo);
       vp[u] = *(const uint2v *)(a.pred + po);
+#else
+      vo[u] = uint2v{(uint32_t)oo, 0u}; vp[u] = uint2v{(uint32_t)po, 1u};
+#endif
     }
   };
-  auto commit_raw = [&](int n) {
-    int nflat = 0;  // wave-uniform: own quads that are near-constant in both planes the network sees (flat_stat_kernel's statistic)
+  auto commit_raw = [&](int k) {
+#ifdef KO_SB_COMMIT
+    return;
+#endif
+    int tx, ty, n;
+    tile_decode(k, tx, ty, n);
+    uint32_t *raw = rawbuf(k);
+    int nflat = 0;  // wave-uniform: own quads that are coherent in both planes the network sees (flat_stat_kernel's statistic)
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const bool item = rdst[u] >= 0;
       const bool zf = rdst[u] & (1 << 30);
       const int d = rdst[u] & ~(3 << 29);
-      uint32_t w[4];
+      uint4v w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int16_t o = (int16_t)(vo[u][j >> 1] >> (16 * (j & 1))), q = (int16_t)(vp[u][j >> 1] >> (16 * (j & 1)));
@@ -2537,142 +2558,212 @@ __global__ __launch_bounds__(512, CFG_STEMB_MINW) void stem_block_kernel(const S
       }
       if (a.flat) nflat += __builtin_popcountll(__ballot(item && (rdst[u] & (1 << 29)) && quad_near_flat(w[0], w[1], w[2], w[3])));
       if (!item) continue;
-      uint2v ev, od;  // parity-split columns: pixels 0, 2 -> even half, 1, 3 -> odd half (8-byte stores)
-      ev[0] = w[0]; ev[1] = w[2]; od[0] = w[1]; od[1] = w[3];
-      *(uint2v *)(raw + d) = ev;
-      *(uint2v *)(raw + d + HW) = od;
+      *(uint4v *)(raw + d) = w;  // row-major: one 16-byte store per quad
     }
     if (a.flat && nflat && lane == 0) atomicAdd(a.flat + n, nflat);  // integer adds: order-independent, deterministic
   };
-  auto tap = [&](int u, int v) { return u * RP + (v & 1) * HW + (v >> 1); };
-  auto main_off = [&](int slot) { return tap(slot / 5, slot % 5); };
+  // 16 contiguous bytes at an 8-byte aligned LDS address (two ds_read_b64 / one ds_read2_b64)
+  auto read16 = [&](const uint32_t *raw, uint32_t dword_index) -> half8 {
+    const uint2v lo = *(const uint2v *)(raw + dword_index), hi = *(const uint2v *)(raw + dword_index + 2);
+    uint4v v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return *(half8 *)&v;
+  };
 
-  int t = blockIdx.x;
-  if (t < ntiles) issue_raw(t);
-  PH_DECL;
-  for (; t < ntiles; t += gridDim.x) {
-    int tx, ty, n;
-    tile_decode(t, tx, ty, n);
-    PH_MARK(7);
-    commit_raw(n);
-    PH_MARK(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    PH_MARK(1);
-    const int t_next = t + gridDim.x;
-    if (t_next < ntiles) issue_raw(t_next);
-    PH_MARK(2);
+  // ---- prologue: raw patch of tile 0 committed, loads of tile 1 in flight ----
+  issue_raw(0);
+  commit_raw(0);
+  if (nloc > 1) issue_raw(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);  // (the resident-weight / border DMA of this wave as well; the prefetch of tile 1 is re-waited by its commit)
+  __builtin_amdgcn_s_barrier();
 
-    // ---- phase 1: t on tile + halo (18 x 34 = 612 pixels = 20 blocks), composed 5x5 stride-2 conv -> T (fp16, LDS) ----
-    for (int pb = wave; pb * 32 < T_H * T_W; pb += NW) {
-      const int m = pb * 32 + p;
-      const bool ok = m < T_H * T_W;
-      const int mm = ok ? m : 0;
-      const int y1 = mm / T_W, x1 = mm - y1 * T_W;
-      const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;  // position in the H x H map
-      const int o = (2 * y1) * RP + x1;                         // window origin = input (2gy-2, 2gx-2)
-      const bool top = gy == 0, left = gx == 0;
-      constexpr int orow0 = 4 * RP;                              // raw row of input row 0 (tiles with ty == 0)
-      auto slot_val = [&](int slot) -> uint32_t {                // K slot of the composed conv (see stem5_kernel)
-        if (slot < 25) return raw[o + main_off(slot)];
-        if (slot < 30) { const uint32_t v = raw[top ? orow0 + x1 + tap(0, slot - 25) : o]; return top ? v : 0u; }
-        if (slot < 35) { const uint32_t v = raw[left ? o + (slot - 30) * RP + 1 : o]; return left ? v : 0u; }
-        if (slot == 35) { const uint32_t v = raw[(top && left) ? orow0 + 2 : o]; return (top && left) ? v : 0u; }
-        return 0u;
-      };
-      float16v acc;
+  if (wave < NWS) {
+    // ================= producer waves: phase 1 of tile k =================
+    // composed first-layer weights (5 k-steps): registers, once per kernel; first use in front of the loop (a first use inside it would
+    // make the compiler drain the raw-plane prefetch with s_waitcnt vmcnt(0) every iteration)
+    half8 am[5];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // all 20 gathered dwords of the block first, then the five MFMAs back to back: interleaved (4 reads, full wait, 1 MFMA) the
-      // LDS latency was exposed five times per block with the matrix pipe idle in between
-      half8 bk[5];
+    for (int k = 0; k < 5; ++k) am[k] = *(const half8 *)((const char *)a.w + k * 1024 + lane * 16);
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {
-        uint32_t *bw = (uint32_t *)&bk[ks];
+    for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(am[k]));
+    for (int k = 0; k <= nloc; ++k) {
+      if (k + 1 < nloc) commit_raw(k + 1);
+      if (k + 2 < nloc) issue_raw(k + 2);
+#ifdef KO_SB_P1
+      if (false) {
+#else
+      if (k < nloc) {
+#endif
+        int tx, ty, n;
+        tile_decode(k, tx, ty, n);
+        const uint32_t *raw = rawbuf(k);
+        char *T = Tb + (k & 1) * TBYTES;
+        // t on tile + halo (18 x 34 = 612 pixels = 20 blocks), composed 5x5 stride-2 conv -> T (fp16, LDS).  Blocks 0..17: one T row each,
+        // columns 0..31 (the lanes' 16-byte reads tile 512 contiguous bytes of a raw row: conflict-free).  Blocks 18, 19: columns 32, 33.
+        // Software-pipelined: the five fragment reads of the wave's NEXT block are issued before the current block's epilogue, so the
+        // LDS round trip hides under ~100 VALU instructions instead of stalling the wave (the producer waves run 1 per SIMD).
+        auto block_pos = [&](int pb, bool &ok, int &y1, int &x1) {
+          const int m = (pb - T_H) * 32 + p;  // blocks 18, 19: index into the 2 x 18 leftover pixels
+          ok = pb < T_H || m < 2 * T_H;
+          y1 = pb < T_H ? pb : (ok ? m >> 1 : 0);
+          x1 = pb < T_H ? p : 32 + (m & 1);
+        };
+        half8 bk[5];
+        auto fetch = [&](int pb) {
+          bool ok; int y1, x1;
+          block_pos(pb, ok, y1, x1);
+          const uint32_t o = (2 * y1) * RP + 2 * x1 + 4 * h;  // window origin = input (2gy-2, 2gx-2); this lane: columns +4h .. +4h+3
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ks < 3) bw[e] = raw[o + (h ? main_off(8 * ks + 4 + e) : main_off(8 * ks + e))];
-          else { const uint32_t v0 = slot_val(8 * ks + e), v1 = slot_val(8 * ks + 4 + e); bw[e] = h ? v1 : v0; }
+          for (int dy = 0; dy < 5; ++dy) bk[dy] = read16(raw, o + dy * RP);
+        };
+        fetch(wave);
+        for (int pb = wave; pb < T_H + 2; pb += NWS) {
+          bool ok; int y1, x1;
+          block_pos(pb, ok, y1, x1);
+          const int gy = ty * TH - 1 + y1, gx = tx * TW - 1 + x1;  // position in the H x H map
+          float16v acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#ifndef KO_SB_P1MFMA
+#pragma unroll
+          for (int dy = 0; dy < 5; ++dy) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[dy], bk[dy], acc, 0, 0, 0);
+#else
+          acc[0] = (float)bk[0][0] + (float)bk[1][1] + (float)bk[2][2] + (float)bk[3][3] + (float)bk[4][4];
+#endif
+          // border corrections (tiles on the picture's top row / left column only; wave-uniform tests)
+          if (ty == 0 || tx == 0) {
+            const bool topb = ok && gy == 0, leftb = ok && gx == 0;
+            if (__ballot(leftb) != 0ull) {  // Left[u] x in(2y-2+u, 0) = window (dy = u, dx = 2); Corner x in(0, 0)
+              const uint32_t l4 = raw[(2 * y1 + 4) * RP + 2 * x1 + 2], c0 = raw[4 * RP + 4];
+              uint4v b;
+              if (h == 0) {
+                b[0] = ((const uint32_t *)&bk[0])[2]; b[1] = ((const uint32_t *)&bk[1])[2];
+                b[2] = ((const uint32_t *)&bk[2])[2]; b[3] = ((const uint32_t *)&bk[3])[2];
+              } else {
+                b[0] = l4; b[1] = topb ? c0 : 0u; b[2] = 0u; b[3] = 0u;
+              }
+              if (!leftb) b = uint4v{0u, 0u, 0u, 0u};
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8 *)(WB + lane * 16), *(half8 *)&b, acc, 0, 0, 0);
+            }
+            if (__ballot(topb) != 0ull) {  // Top[v] x in(0, 2x-2+v) = window (dy = 2, dx = v)
+              uint4v b = *(const uint4v *)&bk[2];
+              if (h == 1) { b[1] = 0u; b[2] = 0u; b[3] = 0u; }
+              if (!topb) b = uint4v{0u, 0u, 0u, 0u};
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8 *)(WB + 1024 + lane * 16), *(half8 *)&b, acc, 0, 0, 0);
+            }
+          }
+          if (pb + NWS < T_H + 2) fetch(pb + NWS);  // next block's fragments fly under this block's epilogue
+          const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;  // outside: conv2's zero padding
+          const uint32_t keep_mask = inside ? 0xFFFFFFFFu : 0u;
+          half4 ov[4];
+          static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const float4v b1q = *(const float4v *)(BL + 4 * h + 8 * q);
+            const half4 none{};
+            ov[q] = act_quad<q>(acc, a.acc_scale, b1q, false, none, true);  // relu(acc * scale + bias), packed arithmetic
+            ((uint32_t *)&ov[q])[0] &= keep_mask;
+            ((uint32_t *)&ov[q])[1] &= keep_mask;
+          });
+          // 16-byte stores (pair16: lanes 0-31 take channels 16qq..+7, lanes 32-63 the next 8): conflict-free at an 80-byte pixel pitch
+          char *dst = T + (y1 * T_W + x1) * PS + 16 * h;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const uint4v w = pair16(ov[2 * qq], ov[2 * qq + 1]);  // every lane takes part in the swap
+            if (ok) *(uint4v *)(dst + 32 * qq) = w;
+          }
         }
       }
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) asm volatile("" : "+v"(bk[ks]));  // keeps the loads above the first MFMA
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ks], bk[ks], acc, 0, 0, 0);
-      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < H;  // outside: conv2's zero padding
-      // (16-byte paired stores and row-wise blocks as in block32_kernel were measured slower here: the kernel sits at 256 VGPRs)
-      if (ok) {
-        char *dst = T + (y1 * T_W + x1) * PS + 8 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 ov;
-          const float4v b1q = *(const float4v *)(BL + 4 * h + 8 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = inside ? (_Float16)fmaxf(acc[4 * q + e] * a.acc_scale + b1q[e], 0.f) : (_Float16)0.f;
-          *(half4 *)(dst + 16 * q) = ov;
-        }
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    PH_MARK(3);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    PH_MARK(4);
-
-    // ---- phase 2: conv2(t) from T + shortcut (composed 3x3 stride-2 conv of the raw planes, fp32) + relu -> b0 ----
-    for (int pb = wave; pb < TH * TW / 32; pb += NW) {
-      const int y = pb, x = p;
-      float16v acc, accs;
+  } else {
+    // ================= consumer waves: phase 2 of tile k - 1 =================
+    // conv2's 18 A fragments and the shortcut's 2 live in this wave's registers for the whole kernel: only activation fragments are
+    // read from LDS in the MFMA loop
+    half8 wf[18], as[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accs[r] = 0.f; }
-      {
-        const int base = (y * T_W + x) * PS + h * 16;
-        auto frag = [&](int item) -> half8 {
+    for (int i = 0; i < 18; ++i) wf[i] = *(const half8 *)(W2 + i * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) as[k] = *(const half8 *)((const char *)a.w + (5 + k) * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) asm volatile("" ::"v"(as[k]));
+    const int cw = wave - NWS;
+    for (int k = 0; k <= nloc; ++k) {
+      if (k + 1 < nloc) commit_raw(k + 1);
+      if (k + 2 < nloc) issue_raw(k + 2);
+#ifdef KO_SB_P2
+      if (false) {
+#else
+      if (k >= 1) {
+#endif
+        int tx, ty, n;
+        tile_decode(k - 1, tx, ty, n);
+        const uint32_t *raw = rawbuf(k - 1);
+        const char *T = Tb + ((k - 1) & 1) * TBYTES;
+        // conv2(t) from T + shortcut (composed 3x3 stride-2 conv of the raw planes, fp32) + relu -> b0.  The consumer waves run one per
+        // SIMD, so LDS latency is hidden by depth, not by other waves: activation fragments are read PD items ahead of the MFMA that
+        // consumes them, and the first PD fragments of the wave's next block are issued before the current block's epilogue.
+        constexpr int PD = 8;
+        half8 bf[PD], sb0, sb1;
+        auto frag = [&](int pb, int item) -> half8 {
+          const int base = (pb * T_W + p) * PS + h * 16;
           const int tp = item >> 1, ks = item & 1, dy = tp / 3, dx = tp - dy * 3;
           return *(const half8 *)(T + base + (dy * T_W + dx) * PS + ks * 32);
         };
-        // weight fragments from the resident LDS copy (this kernel is VGPR-bound: biases + composed weights + prefetch)
-        half8 bf[3], af[3];
-        bf[0] = frag(0); af[0] = *(const half8 *)(W2 + lane * 16);
-        bf[1] = frag(1); af[1] = *(const half8 *)(W2 + 1024 + lane * 16);
+        auto prefetch = [&](int pb) {
+          // shortcut taps (by, bx) at input (2gy+by-1, 2gx+bx-1) = raw (2y+3+by, 2x+3+bx): lanes h = 0 / 1 read rows by = 0 / 1 (k-step 5),
+          // every lane row by = 2 (k-step 6, upper half: zero weights), columns 2x+2 .. 2x+5 (the first one carries a zero weight)
+          sb0 = read16(raw, (2 * pb + 3 + h) * RP + 2 * p + 2);
+          sb1 = read16(raw, (2 * pb + 5) * RP + 2 * p + 2);
 #pragma unroll
-        for (int item = 0; item < 18; ++item) {
-          if (item + 2 < 18) {
-            bf[(item + 2) % 3] = frag(item + 2);
-            af[(item + 2) % 3] = *(const half8 *)(W2 + (item + 2) * 1024 + lane * 16);
+          for (int i = 0; i < PD; ++i) bf[i] = frag(pb, i);
+        };
+        prefetch(cw);
+        for (int pb = cw; pb < TH * TW / 32; pb += NWS) {
+          const int y = pb, x = p;
+          float16v acc, accs;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accs[r] = 0.f; }
+          accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[0], sb0, accs, 0, 0, 0);
+          accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[1], sb1, accs, 0, 0, 0);
+#pragma unroll
+          for (int item = 0; item < 18; ++item) {
+            const half8 cur = bf[item % PD];
+            if (item + PD < 18) bf[item % PD] = frag(pb, item + PD);
+#ifndef KO_SB_P2MFMA
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[item], cur, acc, 0, 0, 0);
+#else
+            acc[item & 15] += (float)cur[0] * (float)wf[item][0];
+#endif
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[item % 3], bf[item % 3], acc, 0, 0, 0);
+          if (pb + NWS < TH * TW / 32) prefetch(pb + NWS);  // next block's first fragments fly under this block's epilogue
+          half4 hq[4];
+          static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const float4v bq = *(const float4v *)(BL + 32 + 4 * h + 8 * q);
+#pragma unroll
+            for (int ep = 0; ep < 2; ++ep) {  // relu(conv2 + (shortcut * scale + bias)), the sum in fp32, packed arithmetic
+              const float2v c2 = {acc[4 * q + 2 * ep], acc[4 * q + 2 * ep + 1]}, s2 = {accs[4 * q + 2 * ep], accs[4 * q + 2 * ep + 1]};
+              const float2v b2 = {bq[2 * ep], bq[2 * ep + 1]};
+              const float2v x2 = c2 + (s2 * a.acc_scale + b2);
+              half2v h2 = __builtin_convertvector(x2, half2v);
+              h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
+              hq[q][2 * ep] = h2[0];
+              hq[q][2 * ep + 1] = h2[1];
+            }
+          });
+          const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * 32 + (size_t)(tx * TW + x) * 32 + 8 * h;
+#ifndef KO_SB_STORE
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
+#else
+          if (hq[0][0] == (_Float16)12345.f) *(uint4v *)((_Float16 *)a.y + ob) = pair16(hq[0], hq[1]);
+#endif
         }
       }
-      {
-        const int o = (2 * (y + 1)) * RP + x + 1;  // this pixel's window origin in the raw patch (t-region coords y+1, x+1)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          half8 b;
-          uint32_t *bw = (uint32_t *)&b;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int t0 = 8 * ks + e, t1 = 8 * ks + 4 + e;
-            const uint32_t v0 = t0 < 9 ? raw[o + tap(1 + t0 / 3, 1 + t0 % 3)] : 0u;
-            const uint32_t v1 = t1 < 9 ? raw[o + tap(1 + t1 / 3, 1 + t1 % 3)] : 0u;
-            bw[e] = h ? v1 : v0;
-          }
-          accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[ks], b, accs, 0, 0, 0);
-        }
-      }
-      half4 hq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4v bq = *(const float4v *)(BL + 32 + 4 * h + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hq[q][e] = (_Float16)fmaxf(acc[4 * q + e] + (accs[4 * q + e] * a.acc_scale + bq[e]), 0.f);
-      }
-      const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * 32 + (size_t)(tx * TW + x) * 32 + 8 * h;
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    PH_MARK(5);
-    if (t_next < ntiles) __builtin_amdgcn_s_barrier();  // the next commit overwrites raw, the next phase 1 overwrites T
-    PH_MARK(6);
   }
-  PH_FLUSH(14);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3228,8 +3319,10 @@ hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) 
 }
 
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st) {
-  constexpr int lds = (39 * 72 * 4 + 15) / 16 * 16 + 18 * 34 * 80 + 18 * 1024 + 256;  // raw + T + conv2 weights + biases
-  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(512), lds, st, a);  // 78 KiB: two workgroups per CU
+  constexpr int lds = 3 * (39 * 72 * 4 + 16) + 2 * (18 * 34 * 80) + 18 * 1024 + 256 + 2 * 1024;  // 3 raw + 2 T buffers + conv2 weights + biases + border k-steps = 149 KiB
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(stem_block_kernel, once); e != hipSuccess) return e;
+  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(512), lds, st, a);  // one workgroup per CU, two pipeline stages inside
   return hipGetLastError();
 }
 

@@ -205,6 +205,61 @@ static void pack_stem5(PackedConv &pc, const float *ws, const float *w1, const s
     }
 }
 
+// The same composed first layer, packed for stem_block_kernel (fast arithmetic; round 3).  K is ordered so that a lane's B fragment is
+// 16 CONTIGUOUS bytes of the row-major raw (org, |org-pred|) patch -- one ds_read2_b64 instead of four gathered ds_read_b32:
+//   k-steps 0..4 (main, one per window row dy): slot s = dx = 0..7, pixel (2y-2+dy, 2x-2+dx); weights W5[dy][dx] for dx < 5, ZERO for dx 5..7
+//   k-step  5    (shortcut): slots 0..3 = raw row 2y-1, columns 2x-2..2x+1 (weight 0, Wsc3[0][0..2]); slots 4..7 = row 2y the same way
+//   k-step  6    (shortcut): slots 0..3 = raw row 2y+1; slots 4..7 zero weights
+//   k-step  7    (border, output column 0 / pixel (0,0)): slots 0..4 = Left[0..4], slot 5 = Corner, rest zero
+//   k-step  8    (border, output row 0): slots 0..4 = Top[0..4], rest zero
+// (slot s of a k-step = K entries 2s (org) and 2s+1 (resi); lane half hh supplies slots 4hh .. 4hh+3).  The 25 main taps and the 9
+// shortcut taps are rounded in the order of pack_stem5 (tap-diffused), so every stored fp16 value equals the one stem5_kernel uses.
+static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const std::vector<double> &s1, const float *wsc,
+                        const std::vector<double> &ssc) {
+  auto Ws = [&](int cm, int c, int by, int bx) { return (double)ws[((cm * 2 + c) * 3 + by) * 3 + bx]; };
+  auto W1 = [&](int co, int cm, int ay, int ax) { return (double)w1[((co * 32 + cm) * 3 + ay) * 3 + ax] * s1[co]; };
+  auto Wsc = [&](int co, int cm) { return (double)wsc[co * 32 + cm] * ssc[co]; };
+  const double mul = (double)(float)(1.0 / 1023) * 4096.0;
+  pc.acc_scale = 1.0f / 4096.0f;
+  pc.plane_halves = 9 * 64 * 8;
+  pc.w.assign(pc.plane_halves, 0);
+  auto store = [&](int ks, int slot, int co, int c, double exact, double *err) {
+    const int hh = slot / 4, j = (slot % 4) * 2 + c;
+    const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
+    const double tgt = err ? exact - *err : exact;
+    const uint16_t q = f32_to_f16((float)tgt);
+    if (err) *err += (double)f16_to_f32(q) - exact;
+    pc.w[idx] = q;
+  };
+  for (int co = 0; co < 32; ++co)
+    for (int c = 0; c < 2; ++c) {
+      double w5[5][5] = {}, top[5] = {}, left[5] = {}, corner = 0.0, sc3[3][3] = {};
+      for (int cm = 0; cm < 32; ++cm) {
+        for (int ay = 0; ay < 3; ++ay)
+          for (int ax = 0; ax < 3; ++ax)
+            for (int by = 0; by < 3; ++by)
+              for (int bx = 0; bx < 3; ++bx) w5[ay + by][ax + bx] += W1(co, cm, ay, ax) * Ws(cm, c, by, bx);
+        for (int ax = 0; ax < 3; ++ax)
+          for (int bx = 0; bx < 3; ++bx) top[ax + bx] -= W1(co, cm, 0, ax) * Ws(cm, c, 2, bx);
+        for (int ay = 0; ay < 3; ++ay)
+          for (int by = 0; by < 3; ++by) left[ay + by] -= W1(co, cm, ay, 0) * Ws(cm, c, by, 2);
+        corner += W1(co, cm, 0, 0) * Ws(cm, c, 2, 2);
+        for (int by = 0; by < 3; ++by)
+          for (int bx = 0; bx < 3; ++bx) sc3[by][bx] += Wsc(co, cm) * Ws(cm, c, by, bx);
+      }
+      double err = 0.0;
+      for (int t = 0; t < 25; ++t) store(t / 5, t % 5, co, c, w5[t / 5][t % 5] * mul, &err);
+      for (int v = 0; v < 5; ++v) store(8, v, co, c, top[v] * mul, nullptr);
+      for (int u = 0; u < 5; ++u) store(7, u, co, c, left[u] * mul, nullptr);
+      store(7, 5, co, c, corner * mul, nullptr);
+      double err_sc = 0.0;
+      for (int t = 0; t < 9; ++t) {
+        const int by = t / 3, bx = t % 3;
+        store(by < 2 ? 5 : 6, (by == 1 ? 4 : 0) + bx + 1, co, c, sc3[by][bx] * mul, &err_sc);
+      }
+    }
+}
+
 bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m, std::string &err) {
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
@@ -240,6 +295,12 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
     fold_scale(b, "layer0.0.shortcut.1", 32, ssc, m.stem.bias_sc, err);
     if (!err.empty()) return false;
     pack_stem5(m.stem, ws, w1, s1, wsc, ssc);
+    if (!exact) {  // second packing of the same weights for stem_block_kernel (contiguous B fragments)
+      m.stem_b = PackedConv();
+      m.stem_b.cin = 2; m.stem_b.cout = 32; m.stem_b.taps = 25; m.stem_b.stride = 2; m.stem_b.kc = 32; m.stem_b.ct = 32; m.stem_b.has_sc = true;
+      pack_stem_b(m.stem_b, ws, w1, s1, wsc, ssc);
+      m.stem_b.bias = m.stem.bias; m.stem_b.bias_sc = m.stem.bias_sc;
+    }
   }
   int cin = 32;
   char nm[96];

@@ -46,6 +46,7 @@ struct Model {
   bool exact = false;
   int planes[5] = {0, 0, 0, 0, 0};
   PackedConv stem;
+  PackedConv stem_b;        // fast arithmetic: the composed first layer packed again for stem_block_kernel (mlt_model.cpp: pack_stem_b)
   Block blocks[5][2];
   Head heads[4];
   bool on_device = false;

@@ -49,10 +49,10 @@ enum {
  * exact), 64/32/16 -> exact (few pixels per map, so fp16 rounding is not averaged away by the global pooling, and these
  * models are 5-65x cheaper).  Sizes that run the fast arithmetic are protected by two device-side guards, applied on
  * EVERY entry point (single, batch, device-pointer, deferred):
- *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are NEAR-constant -- the four org values and the
- *                            four |org - pred| values each span <= 8 (10-bit steps): constant areas, +-1 LSB dither, low-contrast
- *                            texture, gentle ramps -- are re-evaluated with the exact arithmetic (their fp16 rounding errors
- *                            are coherent, the global pooling does not average them away);
+ *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are COHERENT -- the four org values and the four
+ *                            |org - pred| values each span <= 8 (10-bit steps) or are linear to within one step: constant areas,
+ *                            +-1 LSB dither, low-contrast texture, ramps -- are re-evaluated with the exact arithmetic (their
+ *                            fp16 rounding errors are coherent, the global pooling does not average them away);
  *   decision guard (opt-in): CUs whose decision-head top-2 margin is below guard_margin are re-evaluated too, so the
  *                            split mode handed to EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
  * Both cost a second (exact) copy of the weights on the device (11 MB). */
@@ -89,9 +89,9 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out);
 
 /* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
  * blob arrives over RCCL broadcast instead of from weights_dir.  A size configured for the fast arithmetic is
- * CALIBRATED here: 64 seeded synthetic CUs in six content classes the flat guard does not catch (texture, i.i.d. uniform,
- * constant org / textured pred, textured org / constant pred, a constant band just under the guard's threshold, steep
- * ramps) run through the fast and the exact arithmetic on the device; the fast arithmetic is kept only if
+ * CALIBRATED here: 96 seeded synthetic CUs in five content classes the flat guard does not catch (texture, i.i.d. uniform,
+ * constant org / textured pred, textured org / constant pred, a constant band just under the guard's threshold) run
+ * through the fast and the exact arithmetic on the device; the fast arithmetic is kept only if
  * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| <= 0.75 x tolerance;
  * otherwise the 128 model tries a middle tier the same way -- fp16 (hi, lo) pairs for the WEIGHTS only, 2 MFMAs per
  * product -- and a size that meets the contract with neither runs exact (mlt_arithmetic reports the outcome).  The

@@ -11,12 +11,14 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (see the CFG_* / KO_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "ko_mask": ["KO_CH_MASK=1"],
-    "ko_ring": ["KO_CH_RING=1"],
-    "ko_barrier": ["KO_CH_BARRIER=1"],
-    "ko_reads": ["KO_CH_READS=1"],
-    "ko_ring_barrier": ["KO_CH_RING=1", "KO_CH_BARRIER=1"],
-    "ko_all": ["KO_CH_RING=1", "KO_CH_BARRIER=1", "KO_CH_MASK=1", "KO_CH_READS=1"],
+    "ko_p1mfma": ["KO_SB_P1MFMA=1"],
+    "ko_p1": ["KO_SB_P1=1"],
+    "ko_p2mfma": ["KO_SB_P2MFMA=1"],
+    "ko_p2": ["KO_SB_P2=1"],
+    "ko_store": ["KO_SB_STORE=1"],
+    "ko_commit": ["KO_SB_COMMIT=1"],
+    "ko_load": ["KO_SB_LOAD=1"],
+    "ko_p1_p2": ["KO_SB_P1=1", "KO_SB_P2=1"],
 }
 
 
@@ -25,9 +27,13 @@ def main():
     pkg = mltcnn_pkg.load()
     if sys.argv[1] == "build":
         os.makedirs(VDIR, exist_ok=True)
-        for name, defs in VARIANTS.items():
+        from concurrent.futures import ThreadPoolExecutor
+        def one(item):
+            name, defs = item
             pkg.build.build_lib(defines=defs, out=os.path.join(VDIR, f"lib_{name}.so"))
-            print("built", name)
+            print("built", name, flush=True)
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("SWEEP_JOBS", "4"))) as ex:
+            list(ex.map(one, VARIANTS.items()))
     else:
         for name in VARIANTS:
             env = dict(os.environ, MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")

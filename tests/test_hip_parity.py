@@ -129,7 +129,7 @@ def test_content_classes_against_oracle(gpu, seed):
                     assert split[i] == ref_split[i], (S.KIND_NAMES[kind], name, i)
     print(f"seed {seed} (tier {tier}):", report)
     if tier != 1:  # the widened guard statistic really catches these classes (exact re-run of every CU)
-        for k in ("dither", "low_contrast", "flat_zero_resi"):
+        for k in ("dither", "low_contrast", "flat_zero_resi", "ramp"):
             assert report[(k, "default")][1] == n, (k, report[(k, "default")])
         assert report[("partial_flat", "default")][1] == 0   # just UNDER the threshold by construction: stays on the main arithmetic
     for _, c in ctxs:
@@ -282,7 +282,7 @@ def test_guards_replace_flagged_cus_with_exact_results_on_every_entry_point(gpu)
 
 
 def test_load_time_calibration_picks_the_arithmetic(gpu):
-    """mlt_load_weights measures fast vs exact on 64 seeded CUs of six content classes: the bench weight set (seed 10) keeps the fast arithmetic, a
+    """mlt_load_weights measures fast vs exact on 96 seeded CUs of five content classes: the bench weight set (seed 10) keeps the fast arithmetic, a
     weight set whose fp16 error is ~4x larger (seed 22: emulated rms 5.5e-4) is switched to exact, and a tight tolerance
     switches any set.  Reloading other weights into the same context re-calibrates and invalidates the captured graph."""
     import oracle
