@@ -13,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 run, tag = sys.argv[1], sys.argv[2]
+STEPS = 2  # scripts/prof_run.py 4096 2
 prof = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(run, "stats", "out_kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(run, "bench_line.json"), os.path.join(prof, f"{tag}_bench_line.json"))
@@ -29,19 +30,20 @@ for d in sorted(glob.glob(os.path.join(run, "pmc", "*/"))):
     if not os.path.exists(f):
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
+    for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0)):
         k = r["Kernel_Name"]
         if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, x in v.items():
+            x = x[-STEPS:]  # the batch launches come last; the load-time calibration runs the same kernels on 16-CU sub-batches first
             rows[k][c] = sum(x) / len(x)
 if rows:
     cols = ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS",
             "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY"]
     with open(os.path.join(prof, f"{tag}_pmc_sq_summary.txt"), "w") as o:
         o.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 scripts/prof_run.py 4096 2  (one pass per counter group, MI355X)\n")
-        o.write("# per-kernel average over dispatches; SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs\n")
+        o.write("# per-kernel average over the LAST 2 dispatches (the 4096-CU batches; calibration launches excluded); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs\n")
         o.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); lds_busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE/8 * 256 CUs)\n")
         o.write("kernel," + ",".join(cols) + ",mfma_util,lds_busy_frac,lds_conflict_frac\n")
         for k, v in rows.items():
