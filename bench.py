@@ -354,12 +354,12 @@ def main():
         "metric": f"CU-inferences/sec (batch {B}, {size}x{size})", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else "f16 (fp32 accumulate)", "data": "synthetic",
+        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else "f16, weights hi+lo in layer2/layer3 (fp32 accumulate)" if tier == 3 else "f16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if size == 128 else 2}]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
                    "batch_per_gpu": B, "cu_size": size, "weights": f"synthetic seed {args.weight_seed} (no trained checkpoint is distributed)",
                    "parallelism": f"shard{world}",
-                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else "hi+lo weights in layer2 / layer3, single pass in layer0 / layer1" if tier == 3 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
                                   "guard_reruns_total": arith["guard_reruns"]}},
         "roofline": roofline,

@@ -41,6 +41,8 @@ struct SizeState {
   bool enabled = false, loaded = false;
   bool exact = false;          // arithmetic `model` runs (after calibration)
   bool w2 = false;             // middle tier: the main path runs `model_exact` with hi+lo weights only; guards as for fast
+  int w2_from = 0;             // ... from this stage on (0: the whole network; 2: layer2 + layer3 only -- "mixed": layer0 / layer1 stay on the
+                               // fused single-pass kernels of `model`, whose share of the error is the smaller one: the deepest head is the worst)
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
   bool calibrated = false;
@@ -305,7 +307,8 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
-  const bool persistent = (pc.gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
+  const int gt = nsplit == 3 ? pc.gt_w2 : pc.gt;  // the hi+lo-weights tier has its own taps-per-step (mlt_conv_cfg)
+  const bool persistent = (gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
   // ring-DMA: one 16-wave or two 8-wave workgroups per CU, counted over all cout tiles
   const int cap = dma == 2 ? wg_cap * ((pc.mt_dma >= 256 || pc.stride == 2) ? 1 : 2) / (pc.cout / pc.ct) : wg_cap;  // stride 2: LDS fits one
   const int grid_x = (persistent && a.ntiles > cap) ? cap : a.ntiles;
@@ -446,10 +449,20 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   return MLT_OK;
 }
 
+// the network in the size's main arithmetic: `model` (fast, or exact when that is the configured / calibrated arithmetic), or -- middle
+// tier -- the exact-packed `model_exact` with hi+lo WEIGHTS only
+struct W2Scope {
+  mlt_ctx *c; bool old;
+  W2Scope(mlt_ctx *ctx, bool v) : c(ctx), old(ctx->w2_now) { c->w2_now = v; }
+  ~W2Scope() { c->w2_now = old; }
+};
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
 // the raw planes as aligned quads, else by flat_stat_kernel)
+// mback != NULL ("mixed" tier): stages >= split_stage run `mback` (an exact-packed model) with hi+lo WEIGHTS on single fp16 activation planes
+// on the per-conv kernels; the stages before it run `m` (fast packing, fused kernels).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
-                long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
+                long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
+                mlt::Model *mback = nullptr, int split_stage = 99) {
   const int S = st.size;
   int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
   if (rc) return rc;
@@ -483,7 +496,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   static const bool no_c16 = std::getenv("MLT_NO_C16") != nullptr;
   static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
   auto wants_chain = [&](int s, int h_in) -> bool {
-    if (s <= 0 || s >= m.n_stages || m.exact || no_chain) return false;
+    if (s <= 0 || s >= m.n_stages || m.exact || no_chain || (mback && s >= split_stage)) return false;
     const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
     const mlt::PackedConv &c2 = m.blocks[s][0].conv2;
     // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
@@ -499,7 +512,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const bool last = s == m.n_stages - 1;
     // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
     // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
-    mlt::Block &B0 = m.blocks[s][0];
+    const bool back = mback && s >= split_stage;  // this stage runs the exact-packed model in hi+lo-weights mode
+    W2Scope stage_scope(ctx, back ? true : ctx->w2_now);
+    mlt::Block &B0 = back ? mback->blocks[s][0] : m.blocks[s][0];
     const int ho = h / 2 > 0 ? h / 2 : 1;
     const size_t lo_in = act_split ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
     const size_t lo_st = act_split ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                      // plane bytes inside the stage
@@ -554,7 +569,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
     }
     // block 1 (identity shortcut)
-    mlt::Block &B1 = m.blocks[s][1];
+    mlt::Block &B1 = back ? mback->blocks[s][1] : m.blocks[s][1];
     static const bool no_fuse = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
     if (s == 0 && !m.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
       if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
@@ -638,15 +653,10 @@ struct Planes {  // the two Pel planes of a batch in device memory (element stri
   bool aligned8() const { return (((uintptr_t)org | (uintptr_t)pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0; }
 };
 
-// the network in the size's main arithmetic: `model` (fast, or exact when that is the configured / calibrated arithmetic), or -- middle
-// tier -- the exact-packed `model_exact` with hi+lo WEIGHTS only
-struct W2Scope {
-  mlt_ctx *c; bool old;
-  W2Scope(mlt_ctx *ctx, bool v) : c(ctx), old(ctx->w2_now) { c->w2_now = v; }
-  ~W2Scope() { c->w2_now = old; }
-};
 int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs, long pred_cs,
              const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
+  if (st.w2 && st.w2_from > 0)  // mixed tier: layer0 / layer1 fused single-pass, layer2 / layer3 with hi+lo weights
+    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_exact, st.w2_from);
   W2Scope w(ctx, st.w2);
   return run_network(ctx, st, st.w2 ? st.model_exact : st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
 }
@@ -792,7 +802,7 @@ void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t>
 // Runs the calibration set through `model` (or, w2: the middle tier) and through the exact arithmetic, 16 CUs at a time (the exact
 // workspace is 5.6 MiB per 128x128 CU), and leaves in st.calib_rms the WORST pooled rms |dlogit| over {each content class, each
 // head} and in st.calib_max the overall maximum.
-int calibrate(mlt_ctx *ctx, SizeState &st, bool w2) {  // w2: price the middle tier (model_exact with hi+lo weights only) instead of `model`
+int calibrate(mlt_ctx *ctx, SizeState &st, bool w2, int w2_from = 0) {  // w2: price a hi+lo-weights tier (whole network, or from stage w2_from on) instead of `model`
   const int S = st.size, n = kCalibN, nl = st.model.n_logits, sub = 16;
   const size_t cs = (size_t)S * S;
   std::vector<int16_t> org, pred;
@@ -814,7 +824,8 @@ int calibrate(mlt_ctx *ctx, SizeState &st, bool w2) {  // w2: price the middle t
       HIP_TRY(ctx, hipMemcpy(d_poc, poc.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
       HIP_TRY(ctx, hipMemcpy(d_qp, qp.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
       int r;
-      {
+      if (w2 && w2_from > 0) r = run_network(ctx, st, st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf, nullptr, &st.model_exact, w2_from);
+      else {
         W2Scope w(ctx, w2);
         r = run_network(ctx, st, w2 ? st.model_exact : st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf);
       }
@@ -856,7 +867,7 @@ int calibrate(mlt_ctx *ctx, SizeState &st, bool w2) {  // w2: price the middle t
   for (int c = 0; c < kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
   for (int h = 0; h < st.model.n_heads; ++h) if (n_head[h]) { const double r = std::sqrt(s2_head[h] / (double)n_head[h]); if (!(r <= worst)) worst = r; }
   if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
-    std::fprintf(stderr, "mltcnn calibration (size %d, %s): rms per class", S, w2 ? "hi+lo weights" : "single pass");
+    std::fprintf(stderr, "mltcnn calibration (size %d, %s): rms per class", S, !w2 ? "single pass" : w2_from > 0 ? "hi+lo weights in layer2 / layer3" : "hi+lo weights");
     for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
     std::fprintf(stderr, " | per head");
     for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
@@ -906,7 +917,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   free_model(st.model); free_model(st.model_exact);
   st.loaded = false;
   st.exact = st.want_exact;
-  st.w2 = false;
+  st.w2 = false; st.w2_from = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
@@ -931,8 +942,17 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
         static const bool no_w2 = std::getenv("MLT_NO_W2") != nullptr;
         bool w2_ok = false;
         if (size == 128 && !no_w2) {
-          if ((rc = calibrate(ctx, st, true))) return fail(rc);
-          w2_ok = within();
+          // first the cheaper "mixed" form -- hi+lo weights for layer2 / layer3 only (the deepest head carries the largest error and half
+          // of the weight-rounding variance sits in those two stages), layer0 / layer1 on the fused single-pass kernels -- then the whole network
+          static const bool no_mixed = std::getenv("MLT_NO_W2_MIXED") != nullptr;
+          if (!no_mixed) {
+            if ((rc = calibrate(ctx, st, true, 2))) return fail(rc);
+            if ((w2_ok = within())) st.w2_from = 2;
+          }
+          if (!w2_ok) {
+            if ((rc = calibrate(ctx, st, true))) return fail(rc);
+            if ((w2_ok = within())) st.w2_from = 0;
+          }
         }
         if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
         else {  // run it exact
@@ -954,7 +974,7 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->w2 ? 2 : 0;
+  out->exact = st->exact ? 1 : st->w2 ? (st->w2_from > 0 ? 3 : 2) : 0;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;
   out->flat_guard = (!st->exact && st->flat_guard) ? 1 : 0;

@@ -43,7 +43,7 @@ struct ConvArgs {
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
 };
 
-struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma, lat; };  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
+struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma, lat, gt_w2; };  // gt_w2 (exact packing only): taps per weight step of the hi+lo-WEIGHTS tier (NSPLIT = 3)  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
 
 struct Stem5Args {
   const int16_t *org, *pred;   // Pel planes

@@ -3137,6 +3137,18 @@ static const CfgRow kCfg[] = {
     {96, 128, 2, {32, 32}, 2, 2, 2, 2, {2, CFG_GTE_S2}},
 };
 
+// hi+lo-WEIGHTS tier (NSPLIT = 3) on the exact packing: layers whose cin chunk is 32 in both packings run the FAST tiling's taps per step --
+// all taps resident + persistent workgroups for the 32-channel layers, 2 taps per ring step for the two big stride-2 layers (two weight
+// planes: 5 taps would not fit the ring) -- instead of the exact tiling's one / three taps, which is sized for the small models' maps
+// (round 3: 32->32 0.83 -> ... ms per launch in this tier).  Must mirror the nsplit == 3 branches of mlt_launch_conv.
+static int w2_gt(int cin, int cout, int stride, int gt_exact) {
+  if (cin == 32 && cout == 32 && stride == 1) return 9;
+  if (cin == 32 && cout == 64 && stride == 2) return CFG_3264_GT;
+  if (cin == 64 && cout == 128 && stride == 2) return 2;
+  if (cin == 128 && cout == 256 && stride == 2) return 2;
+  return gt_exact;
+}
+
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   for (const CfgRow &r : kCfg)
     if (r.cin == cin && r.cout == cout && r.stride == stride) {
@@ -3148,6 +3160,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
       // the variants assume weights packed for 128-cout tiles (64 for the 64-channel layer)
       out->lat = (!exact && r.lat && r.wcb * r.wc == (r.cout == 64 ? 2 : 4)) ? 1 : 0;
       out->gt = r.gt[exact ? 1 : 0];
+      out->gt_w2 = w2_gt(r.cin, r.cout, r.stride, r.gt[1]);
       return true;
     }
   return false;
@@ -3215,6 +3228,13 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
   if (dma && !exact && cin == 64 && cout == 64 && stride == 1)
     return launch_conv_t<64, 64, 1, 9, false, 64, 1, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, 9, 1, CFG_64_DMA_UN, CFG_S1_MINW, true>(a, grid_x, extra_lds, st);
 #endif
+  if (nsplit == 3 && variant == MLT_CONV_DEFAULT) {  // hi+lo-weights tier with its own tiling (w2_gt above)
+    static_assert(CFG_3264_GT == 10, "32->64 stride-2: all ten weight taps resident");
+    if (cin == 32 && cout == 32 && stride == 1) return launch_conv_t<32, 32, 1, 9, false, 32, 3, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 1, 5, 1, false>(a, grid_x, extra_lds, st);
+    if (cin == 32 && cout == 64 && stride == 2) return launch_conv_t<32, 64, 2, 9, true, 32, 3, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, CFG_3264_GT, 1, CFG_3264_UN, 1, false>(a, grid_x, extra_lds, st);
+    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 3, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 2, 5, 1, false>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 3, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 2, 5, 1, false>(a, grid_x, extra_lds, st);
+  }
   CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
   CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, CFG_3264_UN, 3, CFG_32_MINW)
   CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, CFG_GTE_S1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)

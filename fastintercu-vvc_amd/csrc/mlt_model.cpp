@@ -314,7 +314,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
         pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc; pc.exact = exact;
         ConvCfg cfg;
         if (!mlt_conv_cfg(ci, c, stride, exact ? 1 : 0, &cfg)) { err = "no kernel configuration for this layer shape"; return false; }
-        pc.kc = cfg.kc; pc.ct = cfg.ct; pc.mt = cfg.mt; pc.gt = cfg.gt; pc.dma = cfg.dma; pc.mt_dma = cfg.mt_dma; pc.lat = cfg.lat;
+        pc.kc = cfg.kc; pc.ct = cfg.ct; pc.mt = cfg.mt; pc.gt = cfg.gt; pc.gt_w2 = cfg.gt_w2; pc.dma = cfg.dma; pc.mt_dma = cfg.mt_dma; pc.lat = cfg.lat;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, wname);
         const float *w = b.find(nm, (uint64_t)c * ci * 9, err);
         if (!w) return false;
@@ -331,6 +331,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
           w = centre.data();
           pc.taps = 1;
           pc.gt = 1;
+          pc.gt_w2 = 1;
         }
         std::vector<double> scale, scale_sc;
         std::snprintf(nm, sizeof nm, "layer%d.%d.%s", s, bi, bnname);

@@ -15,6 +15,7 @@ namespace mlt {
 struct PackedConv {
   int cin = 0, cout = 0, taps = 0, stride = 1;
   int kc = 0, ct = 0, mt = 0, gt = 0;  // from mlt_conv_cfg(): cin chunk, couts / pixels per tile, taps per step
+  int gt_w2 = 0;                       // exact packing: taps per step when the layer runs in the hi+lo-weights tier (its own tiling where the cin chunk allows)
   int lat = 0;                         // 1: a small-batch variant exists (32 couts x 128 pixels per workgroup, same packed weights)
   int dma = 0, mt_dma = 0;             // LDS-DMA staging variant (0 none, 1 resident weights, 2 weight ring) and its pixels per workgroup
   bool has_sc = false;

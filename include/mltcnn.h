@@ -93,14 +93,17 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out);
  * constant org / textured pred, textured org / constant pred, a constant band just under the guard's threshold) run
  * through the fast and the exact arithmetic on the device; the fast arithmetic is kept only if
  * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| <= 0.75 x tolerance;
- * otherwise the 128 model tries a middle tier the same way -- fp16 (hi, lo) pairs for the WEIGHTS only, 2 MFMAs per
- * product -- and a size that meets the contract with neither runs exact (mlt_arithmetic reports the outcome).  The
+ * otherwise the 128 model tries the middle tiers the same way -- fp16 (hi, lo) pairs for the WEIGHTS only, 2 MFMAs per
+ * product: first for layer2 / layer3 alone (the deepest head carries the largest error; layer0 / layer1 stay on the fused
+ * single-pass kernels), then for the whole network -- and a size that meets the contract with none of them runs exact
+ * (mlt_arithmetic reports the outcome).  The
  * admission is STATISTICAL (synthetic content, Gaussian-tail factor), not a bound: "within 1e-3" is calibrated, not proven. */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 
 /* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
 typedef struct mlt_arith_info {
-  int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations */
+  int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations;
+                             3: (hi, lo) weights in layer2 / layer3 only, layer0 / layer1 single pass on the fused kernels */
   int32_t calibrated;     /* 1: the calibration ran for this size */
   float calib_rms, calib_max; /* |dlogit| of the chosen non-exact tier (or of the fast one if exact was chosen) vs exact over the calibration CUs:
                                  worst rms pooled per content class / per head, and the overall maximum */
