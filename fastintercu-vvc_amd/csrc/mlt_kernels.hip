@@ -1131,11 +1131,7 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
   const char *wsrc = (const char *)a.w + (size_t)ctile * NCHUNK * TT * (KS * CBT * 1024);
   auto issue_ring = [&]() {  // next ring step, if any is left (all waves keep the counters, ring waves move the data)
     if (steps_to_issue <= 0) return false;
-#ifdef KO_RING
-    if (false) {
-#else
     if (ring_wave) {
-#endif
       const char *src = wsrc + (size_t)(ci * TT + gi * GT) * (KS * CBT * 1024);
       char *dst = ring + slot_wr * WCHUNK;
 #pragma unroll
@@ -1158,9 +1154,6 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
   auto dma_piece = [&](int tp, int chunk, int buf, int k) {
     const int piece = (wave - LW0 - NWR) + k * NWP;
     if (piece >= npiece) return;  // wave-uniform; patch waves wait with vmcnt(0), nothing counts their instructions
-#ifdef KO_PATCH
-    return;
-#endif
     int tx, ty, n0;
     tile_decode(tp, tx, ty, n0);
     const int iy0 = ((ty << th_l) * STRIDE) - 1, ix0 = ((tx << tw_l) * STRIDE) - 1;
@@ -1281,18 +1274,11 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
                 hs[j] = (h * 16) ^ (((q >> PIXROW_L) & (SLOTS - 1)) << 4);
               }
             }
-#ifndef KO_READS
             static_for<WCB>([&](auto ii) {
               constexpr int i = decltype(ii)::value;
               lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
             });
             static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
-#else
-#pragma unroll
-            for (int i = 0; i < WCB; ++i) { half8 &r = fa[sl][i]; const uint32_t ad = wb; asm volatile("" : "=v"(r) : "v"(ad)); }
-#pragma unroll
-            for (int j = 0; j < WPB; ++j) { half8 &r = fb[sl][j]; const uint32_t ad = rowa[j] + (hs[j] ^ (ks * 32)); asm volatile("" : "=v"(r) : "v"(ad)); }
-#endif
           };
           issue(std::integral_constant<int, 0>{});
           if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
@@ -1332,24 +1318,13 @@ __global__ __launch_bounds__(64 * (WAVES_C * WAVES_P + NWL), MINW) void conv_rin
         } else if (patch_wave && g == NG - 1) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#ifndef KO_BARRIER
         asm volatile("s_barrier" ::: "memory");
-#endif
         --ahead;
         if (++slot_rd == NBUF) slot_rd = 0;
       }
       cur ^= 1;
     }
 
-#ifdef KO_EPI
-    if (a.n < 0) {  // never true: keeps the accumulators alive
-#pragma unroll
-      for (int i = 0; i < WCB; ++i)
-#pragma unroll
-        for (int j = 0; j < WPB; ++j) ((float16v *)a.y)[tid + i + j] = acc[i][j];
-    }
-    continue;
-#endif
     // ---- epilogue.  Without loader waves the biases and the residual are read here (the CU's other workgroup covers the
     // latency); with them the biases were loaded once per kernel and the residual a chunk ago ----
     if (loader) continue;
@@ -1509,11 +1484,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
   auto issue_ring = [&]() {
     if (steps_to_issue <= 0) return;
     const bool s_step = S2 && r_pos < NS;
-#ifdef KO_CH_RING
-    if (false) {
-#else
     if (ring_wave) {
-#endif
       if (s_step) {
       } else {
         const char *wsrc = (const char *)(r_cv == 0 ? a.cv[0].w : r_cv == 1 ? a.cv[1].w : a.cv[NCONV > 2 ? 2 : 1].w);
@@ -1873,18 +1844,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 }
 #pragma unroll
                 for (int j = 0; j < WPB; ++j) mvs[sl][j] = mcur[j];
-#ifndef KO_CH_READS
                 static_for<WCB>([&](auto ii) {
                   constexpr int i = decltype(ii)::value;
                   lds_read128<((tt * KS + ks) * CBT + i) * 1024>(fa[sl][i], wb);
                 });
                 static_for<WPB>([&](auto jj) { lds_read128<0>(fb[sl][decltype(jj)::value], rowa[decltype(jj)::value] + (hs[decltype(jj)::value] ^ (ks * 32))); });
-#else
-#pragma unroll
-                for (int i = 0; i < WCB; ++i) { half8 &r = fa[sl][i]; const uint32_t ad = wb; asm volatile("" : "=v"(r) : "v"(ad)); }
-#pragma unroll
-                for (int j = 0; j < WPB; ++j) { half8 &r = fb[sl][j]; const uint32_t ad = rowa[j] + (hs[j] ^ (ks * 32)); asm volatile("" : "=v"(r) : "v"(ad)); }
-#endif
               };
               issue(std::integral_constant<int, 0>{});
               if constexpr (NITEM > 1 && FD > 1) issue(std::integral_constant<int, 1>{});
@@ -1901,12 +1865,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
                 for (int j = 0; j < WPB; ++j) {
                   lds_touch(fb[sl][j]);
                   bm[j] = fb[sl][j];
-#if !defined(KO_CH_MASK)
                   if constexpr (!OOBZ) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ((uint32_t *)&bm[j])[e] &= mvs[sl][j];
                   }
-#endif
                 }
 #pragma unroll
                 for (int i = 0; i < WCB; ++i)
@@ -1964,9 +1926,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, MINW) void chain_kernel(con
             if constexpr (RES == 1 && RES_LATE) {  // the residual tile requested above (every wave)
               if (chunk == NCHUNK - 1 && g == NG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-#ifndef KO_CH_BARRIER
             asm volatile("s_barrier" ::: "memory");
-#endif
             PHC_MARK(5 + 3 * cvi);
             --ahead;
             if (++slot_rd == NBUF) slot_rd = 0;
@@ -2467,13 +2427,19 @@ __global__ __launch_bounds__(256) void stem5_kernel(const Stem5Args a) {
 // separates the intervals.  LDS: three raw buffers (tile k+1 being written, k read by phase 1, k-1 read by phase 2's shortcut), two T
 // buffers, conv2's weights (the consumer waves keep their 18 A fragments in registers), biases, border k-steps = 149 KiB.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) {
+#ifndef CFG_SB_NWS
+#define CFG_SB_NWS 4   // waves per pipeline stage (4: 8 waves per workgroup, 2 per SIMD; 8: 16 waves, 4 per SIMD at <= 128 VGPRs)
+#endif
+#ifndef CFG_SB_PD
+#define CFG_SB_PD 8
+#endif
+__global__ __launch_bounds__(128 * CFG_SB_NWS) void stem_block_kernel(const StemBlockArgs a) {
   constexpr int TH = 16, TW = 32, PS = 80;
   constexpr int T_H = TH + 2, T_W = TW + 2;                 // t region: tile + 1-pixel halo
   constexpr int RH = 2 * T_H + 3, RW = 2 * T_W + 3;         // raw patch 39 x 71
   constexpr int RP = 72;                                    // row pitch in dwords (pixels): quads of 4 pixels are 16-byte aligned
   constexpr int RAWBYTES = RH * RP * 4 + 16, TBYTES = T_H * T_W * PS;  // (+16: the zero-weight columns of the last row's reads)
-  constexpr int NT = 512, NWS = 4;                          // waves per pipeline stage
+  constexpr int NWS = CFG_SB_NWS, NT = 128 * NWS;           // waves per pipeline stage, threads
   constexpr int QW = RP / 4, UR = (RH * QW + NT - 1) / NT;  // raw rows are fetched as 18 quads of 4 pixels: 702 items, 2 per lane
   static_assert(RW <= RP && RP % 4 == 0 && RAWBYTES % 16 == 0, "raw pitch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2495,7 +2461,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
     n = mt >> (txs_l + tys_l);
   };
   auto rawbuf = [&](int k) { return (uint32_t *)(smem + (k % 3) * RAWBYTES); };
-  for (int pi = wave; pi < 18; pi += 8) glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
+  for (int pi = wave; pi < 18; pi += 2 * NWS) glds16((const char *)a.w2 + pi * 1024 + lane * 16, W2 + pi * 1024);
   // biases in LDS: BL[0..31] = bias of conv1 (bn1), BL[32..63] = bias of conv2 (bn2) + bias of the shortcut (only ever added together)
   float *BL = (float *)(W2 + 18 * 1024);
   char *WB = (char *)(BL + 64);  // the two border k-steps' A fragments (2 KiB): read only by blocks that contain border pixels
@@ -2529,18 +2495,11 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
       rdst[u] = in_items ? (ry * RP + 4 * qx) | (live ? 0 : 1 << 30) | (own ? 1 << 29 : 0) : -1;
       const size_t oo = live ? (size_t)n * a.org_cu_stride + (size_t)iy * a.org_row_stride + ix : (size_t)n * a.org_cu_stride + ((tid * 4) & (S - 1));
       const size_t po = live ? (size_t)n * a.pred_cu_stride + (size_t)iy * a.pred_row_stride + ix : (size_t)n * a.pred_cu_stride + ((tid * 4) & (S - 1));
-#ifndef KO_SB_LOAD
       vo[u] = *(const uint2v *)(a.org + oo);
       vp[u] = *(const uint2v *)(a.pred + po);
-#else
-      vo[u] = uint2v{(uint32_t)oo, 0u}; vp[u] = uint2v{(uint32_t)po, 1u};
-#endif
     }
   };
   auto commit_raw = [&](int k) {
-#ifdef KO_SB_COMMIT
-    return;
-#endif
     int tx, ty, n;
     tile_decode(k, tx, ty, n);
     uint32_t *raw = rawbuf(k);
@@ -2590,11 +2549,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
     for (int k = 0; k <= nloc; ++k) {
       if (k + 1 < nloc) commit_raw(k + 1);
       if (k + 2 < nloc) issue_raw(k + 2);
-#ifdef KO_SB_P1
-      if (false) {
-#else
       if (k < nloc) {
-#endif
         int tx, ty, n;
         tile_decode(k, tx, ty, n);
         const uint32_t *raw = rawbuf(k);
@@ -2625,12 +2580,8 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
           float16v acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#ifndef KO_SB_P1MFMA
 #pragma unroll
           for (int dy = 0; dy < 5; ++dy) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[dy], bk[dy], acc, 0, 0, 0);
-#else
-          acc[0] = (float)bk[0][0] + (float)bk[1][1] + (float)bk[2][2] + (float)bk[3][3] + (float)bk[4][4];
-#endif
           // border corrections (tiles on the picture's top row / left column only; wave-uniform tests)
           if (ty == 0 || tx == 0) {
             const bool topb = ok && gy == 0, leftb = ok && gx == 0;
@@ -2691,11 +2642,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
     for (int k = 0; k <= nloc; ++k) {
       if (k + 1 < nloc) commit_raw(k + 1);
       if (k + 2 < nloc) issue_raw(k + 2);
-#ifdef KO_SB_P2
-      if (false) {
-#else
       if (k >= 1) {
-#endif
         int tx, ty, n;
         tile_decode(k - 1, tx, ty, n);
         const uint32_t *raw = rawbuf(k - 1);
@@ -2703,7 +2650,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
         // conv2(t) from T + shortcut (composed 3x3 stride-2 conv of the raw planes, fp32) + relu -> b0.  The consumer waves run one per
         // SIMD, so LDS latency is hidden by depth, not by other waves: activation fragments are read PD items ahead of the MFMA that
         // consumes them, and the first PD fragments of the wave's next block are issued before the current block's epilogue.
-        constexpr int PD = 8;
+        constexpr int PD = CFG_SB_PD;
         half8 bf[PD], sb0, sb1;
         auto frag = [&](int pb, int item) -> half8 {
           const int base = (pb * T_W + p) * PS + h * 16;
@@ -2730,11 +2677,7 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
           for (int item = 0; item < 18; ++item) {
             const half8 cur = bf[item % PD];
             if (item + PD < 18) bf[item % PD] = frag(pb, item + PD);
-#ifndef KO_SB_P2MFMA
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[item], cur, acc, 0, 0, 0);
-#else
-            acc[item & 15] += (float)cur[0] * (float)wf[item][0];
-#endif
           }
           if (pb + NWS < TH * TW / 32) prefetch(pb + NWS);  // next block's first fragments fly under this block's epilogue
           half4 hq[4];
@@ -2753,12 +2696,8 @@ __global__ __launch_bounds__(512) void stem_block_kernel(const StemBlockArgs a) 
             }
           });
           const size_t ob = ((((size_t)n << h_l) + ty * TH + y) << h_l) * 32 + (size_t)(tx * TW + x) * 32 + 8 * h;
-#ifndef KO_SB_STORE
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) *(uint4v *)((_Float16 *)a.y + ob + 16 * qq) = pair16(hq[2 * qq], hq[2 * qq + 1]);
-#else
-          if (hq[0][0] == (_Float16)12345.f) *(uint4v *)((_Float16 *)a.y + ob) = pair16(hq[0], hq[1]);
-#endif
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -3342,7 +3281,7 @@ hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t
   constexpr int lds = 3 * (39 * 72 * 4 + 16) + 2 * (18 * 34 * 80) + 18 * 1024 + 256 + 2 * 1024;  // 3 raw + 2 T buffers + conv2 weights + biases + border k-steps = 149 KiB
   static DeviceOnce once;
   if (hipError_t e = ensure_big_lds(stem_block_kernel, once); e != hipSuccess) return e;
-  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(512), lds, st, a);  // one workgroup per CU, two pipeline stages inside
+  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(128 * CFG_SB_NWS), lds, st, a);  // one workgroup per CU, two pipeline stages inside
   return hipGetLastError();
 }
 
