@@ -36,8 +36,11 @@ LOGIT_TOL = 1e-3                     # BASELINE.json north_star
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 20 + 50 steps of ~5 ms.  The first ~15 steps of a process run 1-3 % slower (measured round 3, scripts/steps_ab.py: 10 steps
+    # after 3 warm-ups 808-836 k CU/s, after 20 warm-ups 834 k, 50 after 5: 829-863 k on the same boxes), so a 3 + 10 default under-reported
+    # the steady state the metric is about
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="CUs per GPU per step (BASELINE: 4096)")
     ap.add_argument("--size", type=int, default=SIZE)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (C oracle over the whole batch = full-batch parity, torch port)")

@@ -8,6 +8,7 @@
 // There is NO CPU fallback: without a usable HIP device mlt_init fails with MLT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mltcnn.h"
@@ -48,6 +50,7 @@ struct SizeState {
   bool calibrated = false;
   float calib_rms = 0.f, calib_max = 0.f;
   uint64_t reruns = 0;         // CUs re-evaluated by the guards
+  double guard_us_per_cu = 0.0; // running estimate of (enqueue -> flagged-CU count on the host) per CU of a batch (run_checked's sleep)
   int size = 0, head_index = 0;
   mlt::Model model;
   mlt::Model model_exact;      // fast sizes: exact-arithmetic copy the guards re-evaluate flagged CUs with
@@ -728,14 +731,19 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   int rc = guard_slot(ctx, 0, n, st.model.n_logits, &g);
   if (rc) return rc;
   if ((rc = run_guarded_async(ctx, st, n, pl, d_poc, d_qp, d_split, d_logits, g))) return rc;
-  // Wait for the 4-byte count.  Default: a blocking wait (the host core sleeps for the ~ms the batch takes -- in the encoder host
-  // cores are the scarce resource).  MLT_GUARD_SPIN_WAIT=1 polls the event instead: the caller's next batch is enqueued some tens
-  // of microseconds earlier, at the price of one busy core.
-  static const bool spin = std::getenv("MLT_GUARD_SPIN_WAIT") != nullptr;
+  // Wait for the 4-byte count.  Default: SLEEP for most of the time the batch is expected to take (a running estimate per CU of this
+  // size, learnt from the previous calls), then poll the event for the rest: the host core is idle for all but the last ~0.2 ms of a
+  // 5 ms batch -- in the encoder host cores are the scarce resource -- and the caller's next batch is still enqueued the moment this one
+  // is through (a plain blocking wait wakes up on an interrupt and left the GPU idle for ~0.14 ms per 4096-CU step, 2.8 %).
+  // MLT_GUARD_SPIN_WAIT=1: poll from the start (one busy core); MLT_GUARD_BLOCKING_WAIT=1: hipEventSynchronize on a blocking-sync event.
+  static const int wait_mode = std::getenv("MLT_GUARD_SPIN_WAIT") ? 1 : std::getenv("MLT_GUARD_BLOCKING_WAIT") ? 2 : 0;
   if (!ctx->ev_guard) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_guard, hipEventDisableTiming | hipEventBlockingSync));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_guard, ctx->stream));
-  if (!spin) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_guard));
+  if (wait_mode == 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_guard));
   else {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double expect_us = st.guard_us_per_cu * (double)n;
+    if (wait_mode == 0 && expect_us > 400.0) std::this_thread::sleep_for(std::chrono::microseconds((long)(expect_us - 250.0)));
     hipError_t e;
     while ((e = hipEventQuery(ctx->ev_guard)) == hipErrorNotReady) {
 #if defined(__x86_64__)
@@ -743,6 +751,9 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
 #endif
     }
     HIP_TRY(ctx, e);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (double)n;
+    // (the estimate follows a faster batch at once and a slower one gradually: oversleeping costs GPU time, polling only host time)
+    st.guard_us_per_cu = st.guard_us_per_cu <= 0.0 ? us : us < st.guard_us_per_cu ? us : 0.75 * st.guard_us_per_cu + 0.25 * us;
   }
   const int k = *g.h_count;
   if (k < 0 || k > n) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }

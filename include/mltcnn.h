@@ -127,9 +127,10 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
                       const int32_t *poc, const int32_t *qp, int32_t *split_mode, float *logits);
 
 /* Same with every pointer in DEVICE memory; enqueues on the context's stream; call mlt_synchronize before reading the
- * results.  With a guard active for `size` the call BLOCKS once per chunk (a sleeping wait on an event; MLT_GUARD_SPIN_WAIT=1
- * polls instead) until the chunk's fast pass has delivered the NUMBER of flagged CUs (4 bytes), then enqueues their exact
- * re-evaluation; without guards it never synchronises.  This is the
+ * results.  With a guard active for `size` the call BLOCKS once per chunk until the chunk's fast pass has delivered the NUMBER of
+ * flagged CUs (4 bytes) -- it sleeps for the expected duration of the batch and polls only for the last ~0.2 ms (MLT_GUARD_SPIN_WAIT=1
+ * polls from the start, MLT_GUARD_BLOCKING_WAIT=1 sleeps on the event) -- then enqueues their exact re-evaluation; without guards it
+ * never synchronises.  This is the
  * HBM-resident path bench.py times. */
 int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, const void *d_pred,
                              const void *d_poc, const void *d_qp, void *d_split_mode, void *d_logits);
