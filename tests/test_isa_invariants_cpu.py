@@ -51,3 +51,15 @@ def test_64_channel_chain_spills_stay_out_of_the_step_loops(stats, form):
     deep = [w for w in st["waits"] if w[1] >= 2]
     assert not deep, f"compiler-generated vmcnt waits inside the step loops: {deep[:5]}"
     assert len([w for w in st["waits"] if w[1] >= 1]) <= 4
+
+
+def test_stem_block_pipeline_has_no_scratch_and_no_drain_inside_its_block_loops(stats):
+    """stem_block_kernel (round 3: producer / consumer pipeline): no spills, and the only compiler-made vmcnt waits inside loops are the
+    raw-patch commit's at the top of an interval (tile-loop depth 1) -- none inside the 32-pixel block loops (depth 2), where a wait would
+    stall a wave that has no partner on its SIMD to hide it and would drain the next tile's raw-plane prefetch."""
+    st = _find(stats, "stem_block_kernel")
+    assert st["scratch"] == 0, f"{st['scratch']} scratch ops"
+    deep = [w for w in st["waits"] if w[1] >= 2]
+    assert not deep, f"compiler-generated vmcnt waits inside the block loops: {deep[:5]}"
+    assert 0 < len([w for w in st["waits"] if w[1] == 1]) <= 24   # the commits of the two roles (<= 2 items x 2 planes each, counted)
+    assert st["glds"] >= 2                                          # conv2's weights + the border k-steps arrive by LDS-DMA
