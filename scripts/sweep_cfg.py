@@ -11,8 +11,9 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    "sb_pd4": ["CFG_SB_PD=4"],
-    "chain_fd3": ["CFG_CHAIN_FD=3"],
+    # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
+    "s2_wp8": ["CFG_3264_WP=8"],
+    "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"],
 }
 # (the KO_* knock-out knobs of rounds 1-3 were removed from the kernels at the end of round 3; their results are in DESIGN.md)
 
@@ -32,7 +33,7 @@ def main():
     else:
         for name in VARIANTS:
             env = dict(os.environ, MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")],
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")],
                                  env=env, capture_output=True, text=True).stdout
             line = [l for l in out.splitlines() if l.startswith("{")]
             if not line:
