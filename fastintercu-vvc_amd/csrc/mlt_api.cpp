@@ -743,17 +743,23 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   else {
     const auto t0 = std::chrono::steady_clock::now();
     const double expect_us = st.guard_us_per_cu * (double)n;
-    if (wait_mode == 0 && expect_us > 400.0) std::this_thread::sleep_for(std::chrono::microseconds((long)(expect_us - 250.0)));
-    hipError_t e;
-    while ((e = hipEventQuery(ctx->ev_guard)) == hipErrorNotReady) {
+    const bool slept = wait_mode == 0 && expect_us > 400.0;
+    if (slept) std::this_thread::sleep_for(std::chrono::microseconds((long)(expect_us - 250.0)));
+    hipError_t e = hipEventQuery(ctx->ev_guard);
+    const bool overslept = slept && e != hipErrorNotReady;  // through already on waking up: the true duration is unknown, only "shorter"
+    while (e == hipErrorNotReady) {
 #if defined(__x86_64__)
       for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
 #endif
+      e = hipEventQuery(ctx->ev_guard);
     }
     HIP_TRY(ctx, e);
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (double)n;
-    // (the estimate follows a faster batch at once and a slower one gradually: oversleeping costs GPU time, polling only host time)
-    st.guard_us_per_cu = st.guard_us_per_cu <= 0.0 ? us : us < st.guard_us_per_cu ? us : 0.75 * st.guard_us_per_cu + 0.25 * us;
+    // The estimate must never get stuck above the truth (oversleeping costs GPU time, polling only host time): a wake-up that found the
+    // batch finished shrinks it by 15 % -- so a one-off slow call (first launch: module load, workspace allocation) is forgotten within a
+    // few calls -- and a measured duration (we polled, so `us` is exact) replaces it half-way, or at once when it is shorter.
+    if (overslept) st.guard_us_per_cu *= 0.85;
+    else st.guard_us_per_cu = (st.guard_us_per_cu <= 0.0 || us < st.guard_us_per_cu) ? us : 0.5 * (st.guard_us_per_cu + us);
   }
   const int k = *g.h_count;
   if (k < 0 || k > n) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
