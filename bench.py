@@ -81,11 +81,14 @@ def launch_ranks(args):
 
 
 def source_signature():
-    """sha256 over the kernel + runtime sources: profiles/pmc_traffic.json is only valid for the build it was measured on."""
+    """sha256 over the kernel + runtime sources (every file of csrc/, sorted): profiles/pmc_traffic.json is only valid for the build it was measured on."""
     h = hashlib.sha256()
-    for f in ("mlt_kernels.hip", "mlt_api.cpp", "mlt_model.cpp", "mlt_kernels.h"):
-        with open(os.path.join(ROOT, "fastintercu-vvc_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    csrc = os.path.join(ROOT, "fastintercu-vvc_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc", ".cpp", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()[:16]
 
 
