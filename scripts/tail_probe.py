@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""GPU box: how far out do the tails of |dlogit| go?  The load-time calibration admits an arithmetic on 96 CUs and a Gaussian tail factor
+(5.5 sigma); this measures the tail itself: N CUs per content class through the shipped tier of a weight set and through the exact
+arithmetic (which sits within 1e-5 of the fp32 oracle), max / rms / count of |dlogit| > 1e-3 and the ratio max / rms per class and head.
+usage: python scripts/tail_probe.py [--seeds 10,23,13] [--n 4096] [--n-texture 16384]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mltcnn_pkg  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="10,23,13")
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--n-texture", type=int, default=16384)
+    a = ap.parse_args()
+    pkg = mltcnn_pkg.load()
+    S, size = pkg.synth, 128
+    classes = [("texture", None), ("uniform", S.KIND_UNIFORM), ("org_flat_pred_tex", S.KIND_ORG_FLAT_PRED_TEX),
+               ("org_tex_pred_flat", S.KIND_ORG_TEX_PRED_FLAT), ("partial_flat", S.KIND_PARTIAL_FLAT)]
+    data = {}
+    for name, kind in classes:
+        n = a.n_texture if kind is None else a.n
+        org, pred = S.make_patches_bulk(size, n, 31337) if kind is None else S.make_patches(size, n, 31337 + kind, kind)
+        poc, qp = S.make_scalars(n, 31337 + (kind or 0))
+        data[name] = (org, pred, poc, qp)
+        print(f"generated {name}: {n} CUs", flush=True)
+    heads = [slice(0, 2), slice(2, 5), slice(5, 9)]
+    for seed in [int(v) for v in a.seeds.split(",")]:
+        blob = pkg.weights.synthetic_blob(0, seed)
+        m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob})
+        e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128)
+        ar = m.arithmetic(size)
+        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 mixed, 2 hi+lo weights, 1 exact), calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
+        tot_n = tot_bad = 0
+        worst = 0.0
+        for name, _ in classes:
+            org, pred, poc, qp = data[name]
+            r0 = m.arithmetic(size)["guard_reruns"]
+            s1, l1 = m.predict_batch(org, pred, poc, qp)
+            s2, l2 = e.predict_batch(org, pred, poc, qp)
+            d = np.abs(l1.astype(np.float64) - l2)
+            rms = np.sqrt((d * d).mean())
+            per_head = [np.sqrt((d[:, h] ** 2).mean()) for h in heads]
+            bad = int((d > 1e-3).sum())
+            srt = np.sort(l2[:, heads[2]].astype(np.float64), axis=1)
+            decisive = (srt[:, -1] - srt[:, -2]) > 2e-3
+            flips = int(((s1 != s2) & decisive).sum())
+            tot_n += d.size; tot_bad += bad; worst = max(worst, float(d.max()))
+            print(f"  {name:18s} n {len(org):6d}  max {d.max():.2e}  rms {rms:.2e}  max/rms {d.max() / rms:4.1f}  per head rms " +
+                  " ".join(f"{v:.2e}" for v in per_head) + f"  |d|>1e-3: {bad}  decisive split flips {flips}  guard re-runs {m.arithmetic(size)['guard_reruns'] - r0}", flush=True)
+        print(f"  => {tot_n} logits, {tot_bad} beyond 1e-3, worst {worst:.2e}", flush=True)
+        m.close(); e.close()
+
+
+if __name__ == "__main__":
+    main()
