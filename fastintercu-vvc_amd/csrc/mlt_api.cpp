@@ -42,9 +42,9 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 struct SizeState {
   bool enabled = false, loaded = false;
   bool exact = false;          // arithmetic `model` runs (after calibration)
-  bool w2 = false;             // middle tier: the main path runs `model_exact` with hi+lo weights only; guards as for fast
+  bool w2 = false;             // middle tier: the main path runs `model_w2` (hi+lo weights on single fp16 activations, fused kernels); guards as for fast
   int w2_from = 0;             // ... from this stage on (0: the whole network; 2: layer2 + layer3 only -- "mixed": layer0 / layer1 stay on the
-                               // fused single-pass kernels of `model`, whose share of the error is the smaller one: the deepest head is the worst)
+                               // single-pass kernels of `model`, whose share of the error is the smaller one: the deepest head is the worst)
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
   bool calibrated = false;
@@ -54,6 +54,7 @@ struct SizeState {
   int size = 0, head_index = 0;
   mlt::Model model;
   mlt::Model model_exact;      // fast sizes: exact-arithmetic copy the guards re-evaluate flagged CUs with
+  mlt::Model model_w2;         // hi+lo-weights copy on the fast tiling (MLT_MODEL_W2); built only when the single-pass calibration fails
   bool guards() const { return !exact && (flat_guard || margin_guard) && model_exact.on_device; }
 };
 
@@ -126,7 +127,6 @@ struct mlt_ctx {
   std::string err;
   bool profile = false;
   bool lds_oob_zero = false;  // DS reads beyond the LDS allocation return zeros on this device (probed at init): chain kernels without zero masks
-  bool w2_now = false;  // the network being enqueued runs an exact-packed model with hi+lo WEIGHTS only (2 MFMAs, single activation planes)
   std::map<std::string, ProfAcc> prof;
   std::vector<std::string> prof_order;
 };
@@ -275,10 +275,13 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // that stream all its weights through their LDS one after the other.  The latency variants cut the couts into 32-channel
   // tiles (4x more workgroups, 4x fewer weight bytes each) on the same packed weights.
   static const long lat_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
-  const bool lat = !pc.exact && pc.lat && hout >= 8 && (long)n * hout * hout <= lat_px;
-  const int dma = (pc.exact || lat) ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
+  // hi+lo weights on the fast tiling (MLT_MODEL_W2): its stride-1 layers with >= 64 channels have ONE per-conv form, the 32-cout x 128-pixel
+  // variant (large launches of those layers go through chain_kernel<..., W2>; this is the bit-identical small-launch / fallback form)
+  // (its stride-2 layers share their tiling with the exact packing and run that tier's kernels at any launch size)
+  const bool lat = !pc.exact && pc.lat && hout >= 8 && (pc.w2 ? pc.stride == 1 : (long)n * hout * hout <= lat_px);
+  const int dma = (pc.exact || pc.w2 || lat) ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
   const int MT = lat ? 128 : dma == 2 ? pc.mt_dma : pc.mt;
-  const int nsplit = pc.exact ? (ctx->w2_now ? 3 : 2) : 1;  // (mlt_launch_conv)
+  const int nsplit = pc.exact ? 2 : pc.w2 ? 4 : 1;  // (mlt_launch_conv)
   const int act_planes = nsplit == 2 ? 2 : 1;
   int tw = hout < 32 ? hout : 32;
   int th = MT / tw < hout ? MT / tw : hout;
@@ -310,7 +313,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
-  const int gt = nsplit == 3 ? pc.gt_w2 : pc.gt;  // the hi+lo-weights tier has its own taps-per-step (mlt_conv_cfg)
+  const int gt = (nsplit == 4 && !lat) ? pc.gt_w2 : pc.gt;  // the hi+lo-weights tier has its own taps-per-step (mlt_conv_cfg)
   const bool persistent = (gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
   // ring-DMA: one 16-wave or two 8-wave workgroups per CU, counted over all cout tiles
   const int cap = dma == 2 ? wg_cap * ((pc.mt_dma >= 256 || pc.stride == 2) ? 1 : 2) / (pc.cout / pc.ct) : wg_cap;  // stride 2: LDS fits one
@@ -358,7 +361,7 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18), (double)n * S * S * 4 + px * 32 * 2 * 2, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_stem5(a, pc.exact ? (ctx->w2_now ? 3 : 2) : 1, grid_x, lds, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_stem5(a, pc.exact ? 2 : pc.w2 ? 3 : 1, grid_x, lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if ((rc = debug_dump(ctx, name, y, (size_t)px * 32 * 2))) return rc;
   return debug_dump(ctx, (std::string(name) + "_sc").c_str(), y_sc, (size_t)px * 32 * 2);
@@ -373,6 +376,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
   a.w = m.stem_b.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
   a.flat = d_flat;
+  a.w_lo_off = m.stem_b.plane_halves * 2; a.w2_lo_off = c2.plane_halves * 2; a.scale2 = c2.acc_scale;
   if (d_flat) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
@@ -384,7 +388,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18 + 288), (double)n * S * S * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_stem_block(a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_stem_block(a, m.w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
@@ -392,8 +396,10 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
 // Fused identity BasicBlock of the 32-channel stage (fast arithmetic, H >= 32): conv1 -> LDS -> conv2 + residual.
 int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, void *y) {
   Block32Args a{};
+  const bool w2 = B.conv1.w2;  // hi+lo weights: 8 x 32 tiles (four resident weight planes)
   a.x = x; a.y = y; a.w1 = B.conv1.d_w; a.w2 = B.conv2.d_w; a.bias1 = B.conv1.d_bias; a.bias2 = B.conv2.d_bias;
-  a.n = n; a.h_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
+  a.w1_lo_off = B.conv1.plane_halves * 2; a.w2_lo_off = B.conv2.plane_halves * 2; a.scale1 = B.conv1.acc_scale; a.scale2 = B.conv2.acc_scale;
+  a.n = n; a.h_l = ilog2(h); a.ntiles = n * (h / (w2 ? 8 : 16)) * (h / 32);
   static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
@@ -403,7 +409,7 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * 32 * 9 * 2, px * 32 * 2 * 2 + 2.0 * 18 * 1024, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_block32(a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_block32(a, w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
@@ -419,8 +425,10 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   a.x = s2_in ? s2_in : t; a.nconv = 3; a.y = y; a.gap = gap; a.n = n; a.zero = ctx->zero_page;
   a.x_c16 = x_c16 ? 1 : 0; a.y_c16 = y_c16 ? 1 : 0; a.res0_c16 = sc_c16 ? 1 : 0;
   const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
+  const bool w2 = B0.conv2.w2;  // hi+lo weights: chain_kernel<..., W2> (two planes per ring step)
   for (int k = 0; k < 3; ++k) {
     a.cv[k].w = pcs[k]->d_w; a.cv[k].bias = pcs[k]->d_bias; a.cv[k].acc_scale = pcs[k]->acc_scale; a.cv[k].relu = 1;
+    a.cv[k].w_lo_off = pcs[k]->plane_halves * 2;
   }
   a.cv[0].res_mode = s2_in ? 2 : 1; a.cv[0].res = sc; a.cv[0].save = 1; a.cv[2].res_mode = 2;
   if (c == 64) {  // no room for b0 in registers: conv 0 writes it to HBM (b0_hbm), the last conv reads it back as its residual
@@ -446,23 +454,18 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, flops, bytes, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, w2, a, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
   return MLT_OK;
 }
 
 // the network in the size's main arithmetic: `model` (fast, or exact when that is the configured / calibrated arithmetic), or -- middle
-// tier -- the exact-packed `model_exact` with hi+lo WEIGHTS only
-struct W2Scope {
-  mlt_ctx *c; bool old;
-  W2Scope(mlt_ctx *ctx, bool v) : c(ctx), old(ctx->w2_now) { c->w2_now = v; }
-  ~W2Scope() { c->w2_now = old; }
-};
+// tier -- `model_w2` (hi+lo WEIGHTS on the fast tiling: the W2 forms of the fused kernels)
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
 // the raw planes as aligned quads, else by flat_stat_kernel)
-// mback != NULL ("mixed" tier): stages >= split_stage run `mback` (an exact-packed model) with hi+lo WEIGHTS on single fp16 activation planes
-// on the per-conv kernels; the stages before it run `m` (fast packing, fused kernels).
+// mback != NULL ("mixed" tier): stages >= split_stage run `mback` (the hi+lo-weights model; same single fp16 activation planes, so the two
+// models' stages compose); the stages before it run `m` (single-pass kernels).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
                 mlt::Model *mback = nullptr, int split_stage = 99) {
@@ -473,7 +476,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   char *p = ctx->ws;
   auto carve = [&](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return (void *)r; };
   const int h0 = S / 2 > 0 ? S / 2 : 1;
-  const bool act_split = m.exact && !ctx->w2_now;  // a lo plane behind every activation
+  const bool act_split = m.exact;  // a lo plane behind every activation
   const int nplanes = act_split ? 2 : 1;
   void *pool[4];
   for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2 * nplanes);
@@ -498,26 +501,28 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   static const bool no_chain_s2 = std::getenv("MLT_NO_CHAIN_S2") != nullptr;
   static const bool no_c16 = std::getenv("MLT_NO_C16") != nullptr;
   static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+  auto model_of = [&](int s) -> mlt::Model & { return (mback && s >= split_stage) ? *mback : m; };
   auto wants_chain = [&](int s, int h_in) -> bool {
-    if (s <= 0 || s >= m.n_stages || m.exact || no_chain || (mback && s >= split_stage)) return false;
+    if (s <= 0 || s >= m.n_stages || no_chain) return false;
+    const mlt::Model &mm = model_of(s);
+    if (mm.exact || (mm.w2 && !ctx->lds_oob_zero)) return false;  // (the hi+lo-weights chains exist in the padding-from-beyond-the-LDS form only)
     const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
-    const mlt::PackedConv &c2 = m.blocks[s][0].conv2;
+    const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
     // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
     // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
     static const bool chain64 = std::getenv("MLT_NO_CHAIN64") == nullptr;
     const bool packing_ok = m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3);  // what chain_kernel<C> streams
     return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
-  auto wants_s2 = [&](int s, int h_in) -> bool { return wants_chain(s, h_in) && !no_chain_s2 && m.blocks[s][0].conv1_s2c.d_w != nullptr; };
+  auto wants_s2 = [&](int s, int h_in) -> bool { return wants_chain(s, h_in) && !no_chain_s2 && model_of(s).blocks[s][0].conv1_s2c.d_w != nullptr; };
   bool cur_c16 = false;  // layout of `cur`
   for (int s = 0; s < m.n_stages; ++s) {
     int hout = h, h2;
     const bool last = s == m.n_stages - 1;
     // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
     // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
-    const bool back = mback && s >= split_stage;  // this stage runs the exact-packed model in hi+lo-weights mode
-    W2Scope stage_scope(ctx, back ? true : ctx->w2_now);
-    mlt::Block &B0 = back ? mback->blocks[s][0] : m.blocks[s][0];
+    mlt::Model &ms = model_of(s);  // (mixed tier: the hi+lo-weights model from split_stage on)
+    mlt::Block &B0 = ms.blocks[s][0];
     const int ho = h / 2 > 0 ? h / 2 : 1;
     const size_t lo_in = act_split ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
     const size_t lo_st = act_split ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                      // plane bytes inside the stage
@@ -527,7 +532,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     static const bool no_fuse0 = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
     // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
     const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
-    const bool fused_b0 = s == 0 && !m.exact && ho >= 32 && !no_fuse0 && quad_ok;
+    const bool fused_b0 = s == 0 && !ms.exact && ho >= 32 && !no_fuse0 && quad_ok;
     if (s == 0 && d_flat && !fused_b0) {
       FlatStatArgs fa{};
       fa.org = d_org; fa.pred = d_pred; fa.org_row_stride = org_rs; fa.org_cu_stride = org_cs; fa.pred_row_stride = pred_rs;
@@ -539,13 +544,13 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
     if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;
-      if ((rc = run_stem_block(ctx, m, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
+      if ((rc = run_stem_block(ctx, ms, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
     } else {
       const bool chain = wants_chain(s, h);
       const bool chain_s2 = wants_s2(s, h);  // the stride-2 conv + shortcut join the launch
       if (s == 0) {
         hout = ho;
-        if ((rc = run_stem5(ctx, m.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
+        if ((rc = run_stem5(ctx, ms.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if (chain_s2) hout = ho;
       else {
         // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
@@ -556,7 +561,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
-        if ((rc = run_chain3(ctx, B0, m.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
+        if ((rc = run_chain3(ctx, B0, ms.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
                              cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
         cur = outs[s];
         cur_c16 = out_c16;
@@ -572,9 +577,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
     }
     // block 1 (identity shortcut)
-    mlt::Block &B1 = back ? mback->blocks[s][1] : m.blocks[s][1];
+    mlt::Block &B1 = ms.blocks[s][1];
     static const bool no_fuse = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-    if (s == 0 && !m.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
+    if (s == 0 && !ms.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
       if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
       cur = outs[s];
       h = hout;
@@ -658,10 +663,9 @@ struct Planes {  // the two Pel planes of a batch in device memory (element stri
 
 int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs, long pred_cs,
              const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
-  if (st.w2 && st.w2_from > 0)  // mixed tier: layer0 / layer1 fused single-pass, layer2 / layer3 with hi+lo weights
-    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_exact, st.w2_from);
-  W2Scope w(ctx, st.w2);
-  return run_network(ctx, st, st.w2 ? st.model_exact : st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
+  if (st.w2 && st.w2_from > 0)  // mixed tier: layer0 / layer1 single-pass, layer2 / layer3 with hi+lo weights
+    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_w2, st.w2_from);
+  return run_network(ctx, st, st.w2 ? st.model_w2 : st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
 }
 
 // fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
@@ -713,7 +717,6 @@ int guard_fixup_async(mlt_ctx *ctx, SizeState &st, int k, const Planes &pl, cons
   int32_t *g_split = (int32_t *)(ctx->gstage + 2 * plane + 2 * small);
   float *g_lg = (float *)(ctx->gstage + 2 * plane + 3 * small);
   HIP_TRY(ctx, mlt_launch_guard_gather(ga, ctx->stream));
-  W2Scope exact_now(ctx, false);
   int rc = run_network(ctx, st, st.model_exact, k, ga.g_org, S, (long)cs, ga.g_pred, S, (long)cs, ga.g_poc, ga.g_qp, g_split, g_lg);
   if (rc) return rc;
   GuardScatterArgs sc{};
@@ -841,11 +844,8 @@ int calibrate(mlt_ctx *ctx, SizeState &st, bool w2, int w2_from = 0) {  // w2: p
       HIP_TRY(ctx, hipMemcpy(d_poc, poc.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
       HIP_TRY(ctx, hipMemcpy(d_qp, qp.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
       int r;
-      if (w2 && w2_from > 0) r = run_network(ctx, st, st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf, nullptr, &st.model_exact, w2_from);
-      else {
-        W2Scope w(ctx, w2);
-        r = run_network(ctx, st, w2 ? st.model_exact : st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf);
-      }
+      if (w2 && w2_from > 0) r = run_network(ctx, st, st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf, nullptr, &st.model_w2, w2_from);
+      else r = run_network(ctx, st, w2 ? st.model_w2 : st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf);
       if (r) return r;
       if ((r = run_network(ctx, st, st.model_exact, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_le))) return r;
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -923,7 +923,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   std::string err;
   mlt::Model m;
-  if (!mlt::build_model(blob, bytes, st.want_exact, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  if (!mlt::build_model(blob, bytes, st.want_exact ? mlt::MLT_MODEL_EXACT : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
   if (st.head_index < 0 || st.head_index >= m.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
   // a reload replaces device buffers that captured graphs and in-flight work point to
@@ -931,19 +931,24 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   drop_graphs(ctx, si);
   // (models own device buffers: whatever the state held -- loaded or left over from a failed load -- is released first, and every
   // error path below releases what it uploaded, so a failed reload leaves the size cleanly unloaded instead of leaking)
-  free_model(st.model); free_model(st.model_exact);
+  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
   st.loaded = false;
   st.exact = st.want_exact;
   st.w2 = false; st.w2_from = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
-  auto fail = [&](int rc) { free_model(st.model); free_model(st.model_exact); st.model = mlt::Model(); st.model_exact = mlt::Model(); return rc; };
+  st.model_w2 = mlt::Model();
+  auto fail = [&](int rc) {
+    free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
+    st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model();
+    return rc;
+  };
   int rc = upload_model(ctx, st.model);
   if (rc) return fail(rc);
   if (!st.exact && (st.flat_guard || st.margin_guard || st.calibrate)) {
     mlt::Model me;
-    if (!mlt::build_model(blob, bytes, true, size, me, err)) { ctx->err = "weights (exact copy): " + err; return fail(MLT_ERR_WEIGHTS); }
+    if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_EXACT, size, me, err)) { ctx->err = "weights (exact copy): " + err; return fail(MLT_ERR_WEIGHTS); }
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return fail(rc);
     if (st.calibrate) {
@@ -953,12 +958,16 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       auto within = [&]() { return 5.5f * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance; };
       if (!within()) {
         // single-pass fp16 does not meet the contract for this weight set.  Middle tier: hi+lo WEIGHTS on single fp16 activations
-        // (2 MFMAs per product on the per-conv kernels; the weight rounding is what dominates the fast error), priced the same way;
-        // only the 128 model (its maps are never 1 x 1, the one kernel variant this tier has no instantiation for)
+        // (2 MFMAs per product on the W2 forms of the fused kernels -- a third copy of the weights, on the fast tiling; the weight rounding
+        // is what dominates the fast error), priced the same way; only the 128 model (the small models' error is activation rounding)
         const float rms1 = st.calib_rms, max1 = st.calib_max;
         static const bool no_w2 = std::getenv("MLT_NO_W2") != nullptr;
         bool w2_ok = false;
         if (size == 128 && !no_w2) {
+          mlt::Model mw;
+          if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
+          st.model_w2 = std::move(mw);
+          if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
           // first the cheaper "mixed" form -- hi+lo weights for layer2 / layer3 only (the deepest head carries the largest error and half
           // of the weight-rounding variance sits in those two stages), layer0 / layer1 on the fused single-pass kernels -- then the whole network
           static const bool no_mixed = std::getenv("MLT_NO_W2_MIXED") != nullptr;
@@ -973,6 +982,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
         }
         if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
         else {  // run it exact
+          free_model(st.model_w2);
+          st.model_w2 = mlt::Model();
           st.calib_rms = rms1; st.calib_max = max1;
           free_model(st.model);
           st.model = std::move(st.model_exact);
@@ -1083,7 +1094,7 @@ void mlt_shutdown(mlt_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->prof)
     for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  for (int i = 0; i < 4; ++i) { free_model(ctx->sz[i].model); free_model(ctx->sz[i].model_exact); }
+  for (int i = 0; i < 4; ++i) { free_model(ctx->sz[i].model); free_model(ctx->sz[i].model_exact); free_model(ctx->sz[i].model_w2); }
   for (SingleCu &sg : ctx->single) {
     if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
     if (sg.graph) (void)hipGraphDestroy(sg.graph);

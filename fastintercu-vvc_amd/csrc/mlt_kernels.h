@@ -63,7 +63,10 @@ struct Block32Args {
   void *y;                     // block output [n][H][H][32] fp16
   const void *w1, *w2;         // packed fp16 weights of conv1 / conv2 (18 KiB each, fast mode layout)
   const float *bias1, *bias2;  // folded BN biases
-  int n, h_l, ntiles;          // H = 1 << h_l (>= 32); tiles of 16 x 32 output pixels
+  int n, h_l, ntiles;          // H = 1 << h_l (>= 32); tiles of 16 x 32 output pixels (hi+lo-weights form: 8 x 32)
+  // hi+lo-weights form: byte offsets hi plane -> lo plane, accumulator scales (weights are stored * 2^s)
+  size_t w1_lo_off, w2_lo_off;
+  float scale1, scale2;
 };
 
 struct StemBlockArgs {
@@ -77,6 +80,9 @@ struct StemBlockArgs {
                                // (flat-content guard; same statistic as flat_stat_kernel)
   float acc_scale;             // composed-weight storage scale (2^-12)
   int n, hout_l, ntiles;       // H = 1 << hout_l (>= 32), picture 2H x 2H; tiles of 16 x 32 output pixels
+  // hi+lo-weights form: byte offsets hi plane -> lo plane of w / w2, accumulator scale of conv2
+  size_t w_lo_off, w2_lo_off;
+  float scale2;
 };
 
 // Fused chain of stride-1 3x3 convs on whole samples (chain_kernel): the BasicBlock tail of a stage,
@@ -84,6 +90,7 @@ struct StemBlockArgs {
 // with every intermediate kept on chip (activations in LDS, b0 as the residual in registers).
 struct ChainConv {
   const void *w;       // packed fp16 weights (same packing as the stand-alone conv of this layer)
+  size_t w_lo_off;     // hi+lo-weights form (chain_kernel<..., W2>): byte offset of the lo plane
   const float *bias;   // folded BN bias
   float acc_scale;
   int relu;
@@ -112,7 +119,7 @@ struct ChainArgs {
   int gap_slots, gap_l;
   int n;
 };
-hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, const ChainArgs &a, int grid_x, hipStream_t st);  // oob_zero: see mlt_probe_lds_oob
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, bool w2, const ChainArgs &a, int grid_x, hipStream_t st);  // oob_zero: see mlt_probe_lds_oob; w2: hi+lo weights (two planes, no stride-2 front conv, oob_zero only)
 bool mlt_chain_supported(int c, int h);
 hipError_t mlt_probe_lds_oob(int *d_ok, hipStream_t st);  // *d_ok = 1 iff DS reads beyond the LDS allocation return zeros on this device
 bool mlt_stage_supported(int c, int h);  // ... including the stage's stride-2 conv + shortcut (S2 variant)
@@ -167,9 +174,9 @@ hipError_t mlt_launch_guard_scatter(const GuardScatterArgs &a, hipStream_t st);
 
 enum { MLT_CONV_DEFAULT = 0, MLT_CONV_DMA = 1, MLT_CONV_LATENCY = 2, MLT_CONV_CENTRE = 3 };  // kernel variant of a layer shape
 bool mlt_conv_has_centre_variant(int cin, int cout);  // 1x1 (centre-tap) instantiation for stride-1 layers on 1x1 maps
-hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);  // nsplit: 1 fast, 2 exact, 3 weights hi+lo only
+hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st);  // nsplit: 1 fast, 2 exact, 3 weights hi+lo only (exact tiling), 4 weights hi+lo on the FAST tiling (MLT_MODEL_W2)
 bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st);  // nsplit as mlt_launch_conv
-hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st);
-hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st);     // w2: hi+lo weights (8 x 32 tiles)
+hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -484,6 +484,21 @@ bool mlt_conv_has_centre_variant(int cin, int cout) { return (cin == cout && (ci
 
 // nsplit: 1 fast, 2 exact (weights and activations hi+lo), 3 weights hi+lo only (the tiling of the exact kernels, 2 MFMAs, single activation planes)
 hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int variant, const ConvArgs &a, int grid_x, int extra_lds, hipStream_t st) {
+  if (nsplit == 4) {
+    // hi+lo weights on the FAST tiling (MLT_MODEL_W2).  The stride-2 and 32-channel layers have ONE tiling for both packings (same kc / ct), so
+    // their bytes are those of the exact packing and they run the nsplit == 3 kernels below; the stride-1 layers with >= 64 channels (kc = 64)
+    // run the 32-cout x 128-pixel variants on any launch size -- large launches of those layers go through chain_kernel<..., W2>, and this is
+    // its bit-identical per-conv form: (chunk, tap, k-step, hi, lo) per accumulator.
+    if (stride == 1 && cin == cout && cin >= 64) {
+      if (variant != MLT_CONV_LATENCY) return hipErrorInvalidValue;
+      if (cin == 64) return launch_conv_t<64, 64, 1, 9, false, 64, 3, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);
+      if (cin == 128) return launch_conv_t<128, 128, 1, 9, false, 64, 3, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+      if (cin == 256) return launch_conv_t<256, 256, 1, 9, false, 64, 3, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+      return hipErrorInvalidValue;
+    }
+    if (variant != MLT_CONV_DEFAULT) return hipErrorInvalidValue;
+    nsplit = 3;
+  }
   const bool exact = nsplit >= 2;
   const bool dma = variant == MLT_CONV_DMA;
   if (variant == MLT_CONV_CENTRE && nsplit == 3) return hipErrorInvalidValue;  // (1x1 maps: small-CU models only, which do not use this tier)
@@ -588,15 +603,28 @@ bool mlt_stage_supported(int c, int h) { return (c == 128 && h == 16) || (c == 2
 #ifndef CFG_CHAIN_SPLIT  // 1: ring DMA on the first half of the waves, activation DMA on the second; 0: every wave issues both
 #define CFG_CHAIN_SPLIT 1
 #endif
+#ifndef CFG_CHAINW2_RB   // ring depth of the hi+lo-weights stage chains (32 KiB steps beside a 64 KiB sample: 2 or 3)
+#define CFG_CHAINW2_RB 3
+#endif
 template <class K> static hipError_t launch_chain_t(K kern, DeviceOnce &once, const ChainArgs &a, int grid_x, int threads, int lds, hipStream_t st) {
   if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3(threads), lds, st, a);
   return hipGetLastError();
 }
-hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, const ChainArgs &a, int grid_x, hipStream_t st) {
+hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, bool w2, const ChainArgs &a, int grid_x, hipStream_t st) {
   static_assert(CFG_BIG_GT == 3 && CFG_BIG_WCB == 2 && CFG_BIG_WC == 2, "chain_kernel reads the packing of the stand-alone 128->128 / 256->256 layers");
   constexpr int lds = 64 * 1024 + 2 * (CFG_BIG_GT * 4 * 4 * 1024);  // 64 KiB activation + two 48 KiB weight steps = all of the LDS
-  static DeviceOnce once[10];
+  static DeviceOnce once[13];
+  if (w2) {  // hi+lo-weights forms (MLT_MODEL_W2 packing: the fast tiling, two planes): one tap per ring step, conv padding from beyond the LDS only
+    if (!oob_zero || with_s2 || a.nconv != 3) return hipErrorInvalidValue;
+    if (c == 64 && h == 32)   // 128 KiB sample + 2 x (2 planes x 8 KiB)
+      return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 2, 1, 2, 3, true, false, false, true, true>, once[10], a, grid_x, 512, 128 * 1024 + 2 * 16 * 1024, st);
+    if (c == 128 && h == 16)  // 64 KiB sample + 3 x (2 planes x 16 KiB)
+      return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 1, CFG_CHAINW2_RB, 1, 2, 3, true, false, true, true, true>, once[11], a, grid_x, 512, 64 * 1024 + CFG_CHAINW2_RB * 32 * 1024, st);
+    if (c == 256 && h == 8)
+      return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 1, CFG_CHAINW2_RB, 1, 2, 3, true, false, true, true, true>, once[12], a, grid_x, 512, 64 * 1024 + CFG_CHAINW2_RB * 32 * 1024, st);
+    return hipErrorInvalidValue;
+  }
   // oob_zero: conv padding from DS reads beyond the LDS allocation (the probed default) or from zero masks; the kernels off the default path
   // (chains without the stride-2 front conv, MLT_NO_CHAIN_S2) exist in the masked form only
   if (c == 64 && h == 32 && a.nconv == 3 && !with_s2) {  // 8 waves x (64 couts x 128 pixels), one 128 KiB sample per workgroup, 2 x 16 KiB weight ring
@@ -631,19 +659,32 @@ hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds,
   return hipGetLastError();
 }
 
-hipError_t mlt_launch_block32(const Block32Args &a, int grid_x, hipStream_t st) {
+hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st) {
+  static DeviceOnce once[2];
+  if (w2) {  // 8 x 32 tiles: X 12 x 36, T 10 x 34 pixels at 80 B + two weight planes per conv
+    constexpr int lds = (12 * 36 + 10 * 34) * 80 + 4 * 18 * 1024;
+    if (hipError_t e = ensure_big_lds(block32_kernel<3, true>, once[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL((block32_kernel<3, true>), dim3(grid_x), dim3(512), lds, st, a);
+    return hipGetLastError();
+  }
   constexpr int lds = (20 * 36 + 18 * 34) * 80 + 2 * 18 * 1024;
-  static DeviceOnce once;
-  if (hipError_t e = ensure_big_lds(block32_kernel, once); e != hipSuccess) return e;
-  hipLaunchKernelGGL(block32_kernel, dim3(grid_x), dim3(512), lds, st, a);
+  if (hipError_t e = ensure_big_lds(block32_kernel<4, false>, once[0]); e != hipSuccess) return e;
+  hipLaunchKernelGGL((block32_kernel<4, false>), dim3(grid_x), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
-hipError_t mlt_launch_stem_block(const StemBlockArgs &a, int grid_x, hipStream_t st) {
-  constexpr int lds = 3 * (39 * 72 * 4 + 16) + 2 * (18 * 34 * 80) + 18 * 1024 + 256 + 2 * 1024;  // 3 raw + 2 T buffers + conv2 weights + biases + border k-steps = 149 KiB
-  static DeviceOnce once;
-  if (hipError_t e = ensure_big_lds(stem_block_kernel, once); e != hipSuccess) return e;
-  hipLaunchKernelGGL(stem_block_kernel, dim3(grid_x), dim3(128 * CFG_SB_NWS), lds, st, a);  // one workgroup per CU, two pipeline stages inside
+hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st) {
+  // 3 raw + 2 T buffers + conv2 weights (hi+lo-weights form: its LO plane -- the hi plane lives in the consumer waves' registers) + biases +
+  // border k-steps (one or two planes) = 149 / 151 KiB
+  constexpr int lds = 3 * (39 * 72 * 4 + 16) + 2 * (18 * 34 * 80) + 18 * 1024 + 256 + 2 * 1024;
+  static DeviceOnce once[2];
+  if (w2) {
+    if (hipError_t e = ensure_big_lds(stem_block_kernel<true>, once[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(stem_block_kernel<true>, dim3(grid_x), dim3(128 * CFG_SB_NWS), lds + 2 * 1024, st, a);
+    return hipGetLastError();
+  }
+  if (hipError_t e = ensure_big_lds(stem_block_kernel<false>, once[0]); e != hipSuccess) return e;
+  hipLaunchKernelGGL(stem_block_kernel<false>, dim3(grid_x), dim3(128 * CFG_SB_NWS), lds, st, a);  // one workgroup per CU, two pipeline stages inside
   return hipGetLastError();
 }
 

@@ -106,20 +106,21 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
   const int cin = pc.cin, cout = pc.cout, taps = pc.taps, tt = taps + (w_sc ? 1 : 0);
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
   pc.plane_halves = (size_t)cout * cin * tt;
-  pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
+  const bool two = pc.exact || pc.w2;  // (hi, lo) planes, plain rounding
+  pc.w.assign(pc.plane_halves * (two ? 2 : 1), 0);
   // power-of-two storage scale: largest 2^s <= 2^6 keeping every stored weight below 2^12
   double wmax = 1e-30;
   for (int co = 0; co < cout; ++co) {
     for (size_t k = 0; k < (size_t)cin * taps; ++k) wmax = std::max(wmax, std::fabs((double)w[(size_t)co * cin * taps + k] * scale[co]));
     if (w_sc) for (int ci = 0; ci < cin; ++ci) wmax = std::max(wmax, std::fabs((double)w_sc[(size_t)co * cin + ci] * scale_sc[co]));
   }
-  int sexp = pc.exact ? 6 : 0;
+  int sexp = two ? 6 : 0;
   while (sexp > 0 && wmax * std::ldexp(1.0, sexp) >= 4096.0) --sexp;
   const double wmul = std::ldexp(1.0, sexp);
   pc.acc_scale = (float)std::ldexp(1.0, -sexp);
   auto put = [&](uint16_t &hi_slot, double exact_unscaled, double &err) {
     const double exact = exact_unscaled * wmul;
-    if (pc.exact) {
+    if (two) {
       const uint16_t q = f32_to_f16((float)exact);
       hi_slot = q;
       (&hi_slot)[pc.plane_halves] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
@@ -164,11 +165,12 @@ static void pack_stem5(PackedConv &pc, const float *ws, const float *w1, const s
   const double mul = (double)(float)(1.0 / 1023) * 4096.0;
   pc.acc_scale = 1.0f / 4096.0f;
   pc.plane_halves = 7 * 64 * 8;
-  pc.w.assign(pc.plane_halves * (pc.exact ? 2 : 1), 0);
+  const bool two = pc.exact || pc.w2;
+  pc.w.assign(pc.plane_halves * (two ? 2 : 1), 0);
   auto store = [&](int kstep0, int slot, int co, int c, double exact, double *err) {
     const int k = 2 * slot + c, ks = kstep0 + k / 16, hh = (k % 16) / 8, j = k % 8;
     const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
-    if (pc.exact) {
+    if (two) {
       const uint16_t q = f32_to_f16((float)exact);
       pc.w[idx] = q;
       pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
@@ -222,10 +224,16 @@ static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const 
   const double mul = (double)(float)(1.0 / 1023) * 4096.0;
   pc.acc_scale = 1.0f / 4096.0f;
   pc.plane_halves = 9 * 64 * 8;
-  pc.w.assign(pc.plane_halves, 0);
+  pc.w.assign(pc.plane_halves * (pc.w2 ? 2 : 1), 0);
   auto store = [&](int ks, int slot, int co, int c, double exact, double *err) {
     const int hh = slot / 4, j = (slot % 4) * 2 + c;
     const size_t idx = ((size_t)ks * 64 + hh * 32 + co) * 8 + j;
+    if (pc.w2) {  // (hi, lo) planes, plain rounding: the values pack_stem5 stores for the same mode
+      const uint16_t q = f32_to_f16((float)exact);
+      pc.w[idx] = q;
+      pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
+      return;
+    }
     const double tgt = err ? exact - *err : exact;
     const uint16_t q = f32_to_f16((float)tgt);
     if (err) *err += (double)f16_to_f32(q) - exact;
@@ -260,7 +268,8 @@ static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const 
     }
 }
 
-bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m, std::string &err) {
+bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err) {
+  const bool exact = mode == MLT_MODEL_EXACT, w2 = mode == MLT_MODEL_W2;
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
   if (std::memcmp(h->magic, "MLTW", 4) != 0 || h->version != 1 || h->arch > 1) { err = "not an MLTW v1 blob"; return false; }
@@ -277,6 +286,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
   m = Model();
   m.arch = (int)h->arch;
   m.exact = exact;
+  m.w2 = w2;
   static const int planes_ctu[4] = {32, 64, 128, 256}, planes_cu[5] = {32, 64, 96, 128, 256};  // arch:243-256 / cu arch:63-79
   static const int cls_ctu[3] = {2, 3, 4}, cls_cu[4] = {2, 3, 4, 6};
   m.n_stages = m.arch == 0 ? 4 : 5;
@@ -290,7 +300,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
     if (!ws || !w1 || !wsc) return false;
     std::vector<double> s1, ssc;
     m.stem.cin = 2; m.stem.cout = 32; m.stem.taps = 25; m.stem.stride = 2; m.stem.kc = 32; m.stem.ct = 32; m.stem.has_sc = true;
-    m.stem.exact = exact;
+    m.stem.exact = exact; m.stem.w2 = w2;
     fold_scale(b, "layer0.0.bn1", 32, s1, m.stem.bias, err);
     fold_scale(b, "layer0.0.shortcut.1", 32, ssc, m.stem.bias_sc, err);
     if (!err.empty()) return false;
@@ -298,6 +308,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
     if (!exact) {  // second packing of the same weights for stem_block_kernel (contiguous B fragments)
       m.stem_b = PackedConv();
       m.stem_b.cin = 2; m.stem_b.cout = 32; m.stem_b.taps = 25; m.stem_b.stride = 2; m.stem_b.kc = 32; m.stem_b.ct = 32; m.stem_b.has_sc = true;
+      m.stem_b.w2 = w2;
       pack_stem_b(m.stem_b, ws, w1, s1, wsc, ssc);
       m.stem_b.bias = m.stem.bias; m.stem_b.bias_sc = m.stem.bias_sc;
     }
@@ -311,7 +322,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
       Block &B = m.blocks[s][bi];
       const int bin = bi == 0 ? cin : c, st = bi == 0 ? 2 : 1;  // _make_layer strides [2,1] (arch:265-271)
       auto make = [&](PackedConv &pc, const char *wname, const char *bnname, int ci, int stride, bool with_sc) -> bool {
-        pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc; pc.exact = exact;
+        pc.cin = ci; pc.cout = c; pc.taps = 9; pc.stride = stride; pc.has_sc = with_sc; pc.exact = exact; pc.w2 = w2;
         ConvCfg cfg;
         if (!mlt_conv_cfg(ci, c, stride, exact ? 1 : 0, &cfg)) { err = "no kernel configuration for this layer shape"; return false; }
         pc.kc = cfg.kc; pc.ct = cfg.ct; pc.mt = cfg.mt; pc.gt = cfg.gt; pc.gt_w2 = cfg.gt_w2; pc.dma = cfg.dma; pc.mt_dma = cfg.mt_dma; pc.lat = cfg.lat;
@@ -353,7 +364,7 @@ bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m,
       if (!(s == 0 && bi == 0) &&  // layer0.0.conv1 + shortcut live in the composed first layer (m.stem)
           !make(B.conv1, "conv1.weight", "bn1", bin, st, has_sc)) return false;
       // second packing of the stride-2 conv for the whole-stage kernel: 16-channel chunks, all 10 "taps" of a chunk = one 40 KiB step
-      if (!exact && bi == 0 && s >= 1 && has_sc && B.conv1.taps == 9 && mlt_stage_supported(c, (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1)) {
+      if (!exact && !w2 && bi == 0 && s >= 1 && has_sc && B.conv1.taps == 9 && mlt_stage_supported(c, (size >> (s + 1)) > 0 ? (size >> (s + 1)) : 1)) {
         PackedConv &pc = B.conv1_s2c;
         pc = PackedConv();
         pc.cin = bin; pc.cout = c; pc.taps = 9; pc.stride = 2; pc.has_sc = true; pc.exact = false;

@@ -20,6 +20,8 @@ struct PackedConv {
   int dma = 0, mt_dma = 0;             // LDS-DMA staging variant (0 none, 1 resident weights, 2 weight ring) and its pixels per workgroup
   bool has_sc = false;
   bool exact = false;          // w holds a hi plane followed by a lo plane (fp16 pair per weight)
+  bool w2 = false;             // hi+lo-WEIGHTS tier on the FAST tiling (kc / ct / gt of the single-pass kernels): two planes like `exact`, read by the
+                               // W2 forms of the fused kernels (chain_kernel, stem_block_kernel, block32_kernel) and by conv_mfma_kernel<NSPLIT = 3>
   size_t plane_halves = 0;     // halves per plane
   float acc_scale = 1.f;       // stored weights = folded weights * 2^s; kernels multiply accumulators by 2^-s
                                // (keeps small weights and their lo parts out of fp16's subnormal range)
@@ -45,6 +47,7 @@ struct Head {
 struct Model {
   int arch = 0, n_stages = 0, n_heads = 0, n_logits = 0;
   bool exact = false;
+  bool w2 = false;          // fast tiling, two weight planes (MLT_MODEL_W2)
   int planes[5] = {0, 0, 0, 0, 0};
   PackedConv stem;
   PackedConv stem_b;        // fast arithmetic: the composed first layer packed again for stem_block_kernel (mlt_model.cpp: pack_stem_b)
@@ -53,7 +56,8 @@ struct Model {
   bool on_device = false;
 };
 
-bool build_model(const void *blob, size_t bytes, bool exact, int size, Model &m, std::string &err);  // size: CU size the model will serve
+enum { MLT_MODEL_FAST = 0, MLT_MODEL_EXACT = 1, MLT_MODEL_W2 = 2 };  // tap-diffused single fp16 plane / (hi, lo) planes on the exact tiling / (hi, lo) planes on the fast tiling
+bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err);  // size: CU size the model will serve
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
 
