@@ -28,6 +28,14 @@ namespace {
 std::string g_init_error;
 std::mutex g_mutex;
 
+// Every environment switch of the library except MLT_CALIB_VERBOSE is a tuning / test knob (A/B runs, sweeps, fallback paths): they are
+// honoured only when MLT_TUNING=1 is set as well, so that an encoder process cannot change kernel selection, chunking or wait modes by
+// an accident of its environment.
+const char *tuning_env(const char *name) {
+  const char *e = std::getenv("MLT_TUNING");
+  return (e && e[0] == '1') ? std::getenv(name) : nullptr;
+}
+
 int size_index(int size) {
   switch (size) {
     case 128: return 0;
@@ -43,8 +51,8 @@ struct SizeState {
   bool enabled = false, loaded = false;
   bool exact = false;          // arithmetic `model` runs (after calibration)
   bool w2 = false;             // middle tier: the main path runs `model_w2` (hi+lo weights on single fp16 activations, fused kernels); guards as for fast
-  int w2_from = 0;             // ... from this stage on (0: the whole network; 2: layer2 + layer3 only -- "mixed": layer0 / layer1 stay on the
-                               // single-pass kernels of `model`, whose share of the error is the smaller one: the deepest head is the worst)
+  unsigned w2_mask = 0;        // ... in the stages whose bit is set (bit s = layer s; all four: the whole network); the other stages stay on the
+                               // single-pass kernels of `model` ("mixed" tiers: the calibration picks the CHEAPEST set of stages that meets the contract)
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
   bool calibrated = false;
@@ -72,7 +80,7 @@ struct SingleCu {
   size_t plane = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  const char *ws_at_capture = nullptr;  // the graph bakes in workspace pointers
+  uint64_t ws_gen_at_capture = 0;       // the graph bakes in workspace pointers: valid only for the workspace allocation it was captured on
   hipStream_t stream_at_capture = nullptr;
 };
 
@@ -99,10 +107,12 @@ struct mlt_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   SizeState sz[4];
-  float guard_margin = 0.02f;
+  float guard_margin = 2e-3f;  // decision guard: 2 x tolerance unless configured (mlt_init)
   int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
+  uint64_t ws_gen = 1;  // bumped by every (re)allocation / release of ws: a captured graph is replayed only on the generation it was captured on
+                        // (an equal ADDRESS proves nothing once the workspace can shrink: a later, smaller allocation may land on it)
   char *zero_page = nullptr;  // 64 KiB of zeros: padding source of the LDS-DMA patch staging
   // mlt_predict_batch: second stream + events for the H2D / compute overlap, CUs per staged sub-chunk (MLT_STAGE_CHUNK)
   hipStream_t copy_stream = nullptr;
@@ -210,15 +220,20 @@ size_t ws_per_cu(const mlt::Model &m, int S) {
 int ensure_ws(mlt_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return MLT_OK;
   if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  ++ctx->ws_gen;
   HIP_TRY(ctx, hipMalloc((void **)&ctx->ws, bytes));
   ctx->ws_bytes = bytes;
   return MLT_OK;
+}
+void release_ws(mlt_ctx *ctx) {  // (the caller has synchronised the stream)
+  if (ctx->ws) { (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  ++ctx->ws_gen;
 }
 
 // MLT_DEBUG_DUMP_DIR=<dir>: after every kernel, synchronise and write the output tensor to <dir>/<seq>_<name>.bin
 // (bring-up aid only; never set in production or in timed runs).
 int debug_dump(mlt_ctx *ctx, const char *name, const void *dptr, size_t bytes) {
-  static const char *dir = std::getenv("MLT_DEBUG_DUMP_DIR");
+  static const char *dir = tuning_env("MLT_DEBUG_DUMP_DIR");
   static int seq = 0;
   if (!dir) return MLT_OK;
   std::vector<char> host(bytes);
@@ -274,7 +289,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // Small batches (the encoder's one-CU-per-call use): the throughput tiling would put a whole layer on 1-4 workgroups
   // that stream all its weights through their LDS one after the other.  The latency variants cut the couts into 32-channel
   // tiles (4x more workgroups, 4x fewer weight bytes each) on the same packed weights.
-  static const long lat_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
+  static const long lat_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
   // hi+lo weights on the fast tiling (MLT_MODEL_W2): its stride-1 layers with >= 64 channels have ONE per-conv form, the 32-cout x 128-pixel
   // variant (large launches of those layers go through chain_kernel<..., W2>; this is the bit-identical small-launch / fallback form)
   // (its stride-2 layers share their tiling with the exact packing and run that tier's kernels at any launch size)
@@ -311,7 +326,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   a.ntiles = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
   // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
-  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
   const int gt = (nsplit == 4 && !lat) ? pc.gt_w2 : pc.gt;  // the hi+lo-weights tier has its own taps-per-step (mlt_conv_cfg)
   const bool persistent = (gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
@@ -379,7 +394,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   a.w_lo_off = m.stem_b.plane_halves * 2; a.w2_lo_off = c2.plane_halves * 2; a.scale2 = c2.acc_scale;
   if (d_flat) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
-  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "stem+block_s2_2to32_h%d(layer0.0)", h);
@@ -400,7 +415,7 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   a.x = x; a.y = y; a.w1 = B.conv1.d_w; a.w2 = B.conv2.d_w; a.bias1 = B.conv1.d_bias; a.bias2 = B.conv2.d_bias;
   a.w1_lo_off = B.conv1.plane_halves * 2; a.w2_lo_off = B.conv2.plane_halves * 2; a.scale1 = B.conv1.acc_scale; a.scale2 = B.conv2.acc_scale;
   a.n = n; a.h_l = ilog2(h); a.ntiles = n * (h / (w2 ? 8 : 16)) * (h / 32);
-  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "block_s1_32_h%d(conv1+conv2)", h);
@@ -440,7 +455,7 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   }
   const int hw = h * h;
   a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
-  static const int wg_cap = [] { const char *e = std::getenv("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   const int spw = c == 256 ? 2 : 1;            // samples per workgroup (64 KiB of activations)
   const int ntiles = (n + spw - 1) / spw;
   const int grid_x = ntiles > wg_cap ? wg_cap : ntiles;  // one workgroup per CU (its LDS is full), persistent over tiles
@@ -464,11 +479,11 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
 // tier -- `model_w2` (hi+lo WEIGHTS on the fast tiling: the W2 forms of the fused kernels)
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
 // the raw planes as aligned quads, else by flat_stat_kernel)
-// mback != NULL ("mixed" tier): stages >= split_stage run `mback` (the hi+lo-weights model; same single fp16 activation planes, so the two
-// models' stages compose); the stages before it run `m` (single-pass kernels).
+// mback != NULL (hi+lo-weights tiers): the stages whose bit is set in back_mask run `mback` (the hi+lo-weights model; same single fp16
+// activation planes, so the two models' stages compose freely), the others `m` (single-pass kernels).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
-                mlt::Model *mback = nullptr, int split_stage = 99) {
+                mlt::Model *mback = nullptr, unsigned back_mask = 0) {
   const int S = st.size;
   int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
   if (rc) return rc;
@@ -497,11 +512,11 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   // Which stages run as chain / whole-stage launches (fast arithmetic, large launches; small ones keep the per-conv latency
   // variants: a chain runs its convs one after the other on n workgroups).  Asked for stage s AND for stage s + 1: a stage
   // whose successor is a whole-stage kernel writes its output chunk-major (ConvArgs.y_c16).
-  static const bool no_chain = std::getenv("MLT_NO_CHAIN") != nullptr || std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
-  static const bool no_chain_s2 = std::getenv("MLT_NO_CHAIN_S2") != nullptr;
-  static const bool no_c16 = std::getenv("MLT_NO_C16") != nullptr;
-  static const long chain_min_px = [] { const char *e = std::getenv("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
-  auto model_of = [&](int s) -> mlt::Model & { return (mback && s >= split_stage) ? *mback : m; };
+  static const bool no_chain = tuning_env("MLT_NO_CHAIN") != nullptr || tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
+  static const bool no_chain_s2 = tuning_env("MLT_NO_CHAIN_S2") != nullptr;
+  static const bool no_c16 = tuning_env("MLT_NO_C16") != nullptr;
+  static const long chain_min_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+  auto model_of = [&](int s) -> mlt::Model & { return (mback && ((back_mask >> s) & 1u)) ? *mback : m; };
   auto wants_chain = [&](int s, int h_in) -> bool {
     if (s <= 0 || s >= m.n_stages || no_chain) return false;
     const mlt::Model &mm = model_of(s);
@@ -510,7 +525,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
     // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
     // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
-    static const bool chain64 = std::getenv("MLT_NO_CHAIN64") == nullptr;
+    static const bool chain64 = tuning_env("MLT_NO_CHAIN64") == nullptr;
     const bool packing_ok = m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3);  // what chain_kernel<C> streams
     return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
@@ -521,7 +536,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const bool last = s == m.n_stages - 1;
     // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
     // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
-    mlt::Model &ms = model_of(s);  // (mixed tier: the hi+lo-weights model from split_stage on)
+    mlt::Model &ms = model_of(s);  // (hi+lo-weights tiers: the two-plane model for the stages of the mask)
     mlt::Block &B0 = ms.blocks[s][0];
     const int ho = h / 2 > 0 ? h / 2 : 1;
     const size_t lo_in = act_split ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
@@ -529,7 +544,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     ConvIO io;
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
     io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
-    static const bool no_fuse0 = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+    static const bool no_fuse0 = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
     // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
     const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
     const bool fused_b0 = s == 0 && !ms.exact && ho >= 32 && !no_fuse0 && quad_ok;
@@ -578,7 +593,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
     // block 1 (identity shortcut)
     mlt::Block &B1 = ms.blocks[s][1];
-    static const bool no_fuse = std::getenv("MLT_NO_BLOCK_FUSION") != nullptr;
+    static const bool no_fuse = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
     if (s == 0 && !ms.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
       if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
       cur = outs[s];
@@ -663,9 +678,9 @@ struct Planes {  // the two Pel planes of a batch in device memory (element stri
 
 int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs, long pred_cs,
              const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
-  if (st.w2 && st.w2_from > 0)  // mixed tier: layer0 / layer1 single-pass, layer2 / layer3 with hi+lo weights
-    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_w2, st.w2_from);
-  return run_network(ctx, st, st.w2 ? st.model_w2 : st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
+  if (st.w2)  // hi+lo weights in the stages of w2_mask, single pass in the others
+    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_w2, st.w2_mask);
+  return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
 }
 
 // fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
@@ -686,7 +701,8 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   int off = 0;
   for (int h = 0; h < st.head_index; ++h) off += st.model.heads[h].classes;
   sa.head_off = off; sa.head_classes = st.model.heads[st.head_index].classes;
-  sa.flat_thr = (S * S / 4) / 8;  // >= 1/8 of the quads
+  sa.flat_thr = (S * S / 4) / 8;  // >= 1/8 of the quads exactly flat (constant / exactly linear in both planes)
+  sa.near_thr = (S * S / 4) / 2;  // or >= 1/2 of them near-flat (mlt_kernels.h: MLT_FLAT_RANGE)
   sa.margin = st.margin_guard ? ctx->guard_margin : 0.f;
   if ((rc = L.prof_begin("guard_select", 0.0, 0.0, e0, e1))) return rc;
   HIP_TRY(ctx, mlt_launch_guard_select(sa, ctx->stream));
@@ -739,7 +755,7 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   // 5 ms batch -- in the encoder host cores are the scarce resource -- and the caller's next batch is still enqueued the moment this one
   // is through (a plain blocking wait wakes up on an interrupt and left the GPU idle for ~0.14 ms per 4096-CU step, 2.8 %).
   // MLT_GUARD_SPIN_WAIT=1: poll from the start (one busy core); MLT_GUARD_BLOCKING_WAIT=1: hipEventSynchronize on a blocking-sync event.
-  static const int wait_mode = std::getenv("MLT_GUARD_SPIN_WAIT") ? 1 : std::getenv("MLT_GUARD_BLOCKING_WAIT") ? 2 : 0;
+  static const int wait_mode = tuning_env("MLT_GUARD_SPIN_WAIT") ? 1 : tuning_env("MLT_GUARD_BLOCKING_WAIT") ? 2 : 0;
   if (!ctx->ev_guard) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_guard, hipEventDisableTiming | hipEventBlockingSync));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_guard, ctx->stream));
   if (wait_mode == 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_guard));
@@ -770,20 +786,31 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
 }
 
 // ---- load-time calibration of the fast arithmetic against the exact one (include/mltcnn.h: mlt_load_weights) ----
-// Calibration set (round 3): NOT only the bench's texture distribution.  96 seeded CUs in five content classes -- the classes the
+// Calibration set (round 3): NOT only the bench's texture distribution.  Seeded CUs in five content classes -- the classes the
 // flat-content guard does NOT re-evaluate exactly, because admission must be decided on what the fast arithmetic will really see:
-//   0 texture (blocky base + texture +-48, pred = org + noise +-40; 32 CUs)      1 i.i.d. uniform org and pred (large residuals; 16)
-//   2 constant org / textured pred (16)    3 textured org / constant pred (16)   4 texture with a constant band over 10-12 % of the
-//   quads, just under the guard's 1/8 (16)
+//   0 texture (blocky base + texture +-48, pred = org + noise +-40)      1 i.i.d. uniform org and pred (large residuals)
+//   2 constant org / textured pred    3 textured org / constant pred   4 texture with a constant band over 10-12 % of the
+//   quads, just under the guard's 1/8 for exactly flat quads   5 (round 4) texture with a NEAR-flat band (+-1 LSB dither or amplitude-4
+//   texture on constants, alternating) over 40-48 % of the rows, just under the guard's 1/2 for near-flat quads
 // (content the guard catches -- constant, dithered, low-contrast, ramps -- is evaluated with the exact arithmetic anyway).
-constexpr int kCalibClasses = 5;
-constexpr int kCalibCount[kCalibClasses] = {32, 16, 16, 16, 16};
-constexpr int kCalibN = 96;
+// Round 4: 560 CUs (160 + 5 x 80; round 3: 96) = 5040 logits of the 128 model, so that the LARGEST error seen is a statistic with some power:
+// a Gaussian sample of that size peaks at 3.9 sigma, the round-3 tail probe found weight sets whose worst error sits at 6.5 x their rms.
+constexpr int kCalibClasses = 6;
+constexpr int kCalibCount[kCalibClasses] = {160, 80, 80, 80, 80, 80};
+constexpr int kCalibN = 560;
 
-void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t> &pred, std::vector<int32_t> &poc, std::vector<int32_t> &qp,
-                          std::vector<int> &cls) {
+struct CalibInputs { std::vector<int16_t> org, pred; std::vector<int32_t> poc, qp; std::vector<int> cls; };
+
+// (generated once per process and CU size: 31 MB of planes for S = 128, ~0.1 s of host time)
+const CalibInputs &calibration_set(int S) {
+  static std::mutex mu;
+  static std::map<int, CalibInputs> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(S);
+  if (it != cache.end()) return it->second;
+  CalibInputs &ci = cache[S];
   const size_t cs = (size_t)S * S;
-  org.assign(cs * kCalibN, 0); pred.assign(cs * kCalibN, 0); poc.assign(kCalibN, 0); qp.assign(kCalibN, 0); cls.assign(kCalibN, 0);
+  ci.org.assign(cs * kCalibN, 0); ci.pred.assign(cs * kCalibN, 0); ci.poc.assign(kCalibN, 0); ci.qp.assign(kCalibN, 0); ci.cls.assign(kCalibN, 0);
   uint64_t z = 0x9E3779B97F4A7C15ull;  // splitmix64
   auto next = [&]() { z += 0x9E3779B97F4A7C15ull; uint64_t x = z; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
   auto clip = [](int v) { return v < 0 ? 0 : v > 1023 ? 1023 : v; };
@@ -791,15 +818,17 @@ void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t>
   int i = 0;
   for (int c = 0; c < kCalibClasses; ++c)
     for (int k = 0; k < kCalibCount[c]; ++k, ++i) {
-      cls[i] = c;
-      int16_t *o = &org[(size_t)i * cs], *q = &pred[(size_t)i * cs];
+      ci.cls[i] = c;
+      int16_t *o = &ci.org[(size_t)i * cs], *q = &ci.pred[(size_t)i * cs];
       std::vector<int> base((size_t)nb * nb);
       for (int &b : base) b = 64 + (int)(next() % 896);
       const int co = (int)(next() % 1024), cp = (int)(next() % 1024);
       int band_h = (S * (10 + k % 3)) / 100;
       if (band_h * 8 >= S) band_h = S / 8 - 1;
       if (band_h < 1) band_h = 1;
+      if (c == 5) band_h = (S * (40 + 4 * (k % 3))) / 100;
       const int band_y = (int)(next() % (uint64_t)(S - band_h + 1));
+      const int amp = (k & 1) ? 4 : 1;  // class 5: low contrast / dither
       for (int y = 0; y < S; ++y)
         for (int x = 0; x < S; ++x) {
           int vo, vp;
@@ -810,91 +839,115 @@ void make_calibration_set(int S, std::vector<int16_t> &org, std::vector<int16_t>
             if (c == 2) vo = co;
             if (c == 3) vp = cp;
             if (c == 4 && y >= band_y && y < band_y + band_h) { vo = co; vp = cp; }
+            if (c == 5 && y >= band_y && y < band_y + band_h) {
+              vo = clip(8 + co % 1008 + (int)(next() % (uint64_t)(2 * amp + 1)) - amp);
+              vp = clip(8 + cp % 1008 + (int)(next() % (uint64_t)(2 * amp + 1)) - amp);
+            }
           }
           o[(size_t)y * S + x] = (int16_t)vo;
           q[(size_t)y * S + x] = (int16_t)vp;
         }
-      poc[i] = (int32_t)(next() % 601);
-      qp[i] = 17 + (int32_t)(next() % 31);
+      ci.poc[i] = (int32_t)(next() % 601);
+      ci.qp[i] = 17 + (int32_t)(next() % 31);
     }
+  return ci;
 }
 
-// Runs the calibration set through `model` (or, w2: the middle tier) and through the exact arithmetic, 16 CUs at a time (the exact
-// workspace is 5.6 MiB per 128x128 CU), and leaves in st.calib_rms the WORST pooled rms |dlogit| over {each content class, each
-// head} and in st.calib_max the overall maximum.
-int calibrate(mlt_ctx *ctx, SizeState &st, bool w2, int w2_from = 0) {  // w2: price a hi+lo-weights tier (whole network, or from stage w2_from on) instead of `model`
-  const int S = st.size, n = kCalibN, nl = st.model.n_logits, sub = 16;
-  const size_t cs = (size_t)S * S;
-  std::vector<int16_t> org, pred;
-  std::vector<int32_t> poc, qp;
-  std::vector<int> cls;
-  make_calibration_set(S, org, pred, poc, qp, cls);
-  const size_t plane = cs * 2 * sub, lgb = (size_t)sub * nl * 4;
+// One calibration session of mlt_load_weights: the calibration set resident on the device, its exact logits (computed ONCE, 96 CUs at a
+// time: the exact workspace is 5.6 MiB per 128x128 CU), and price(mask) = the set through `model` with hi+lo weights in the stages of
+// `mask` (0: single pass everywhere), leaving in st.calib_rms the WORST pooled rms |dlogit| over {each content class, each head}, in
+// st.calib_max the overall maximum and in tail_ratio max / (rms pooled over everything).
+struct CalibSession {
+  mlt_ctx *ctx; SizeState &st;
+  const CalibInputs *in = nullptr;
   char *d = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&d, 2 * plane + 3 * (size_t)sub * 4 + 2 * lgb));
-  int16_t *d_org = (int16_t *)d, *d_pred = (int16_t *)(d + plane);
-  int32_t *d_poc = (int32_t *)(d + 2 * plane), *d_qp = d_poc + sub, *d_split = d_qp + sub;
-  float *d_lf = (float *)(d_split + sub), *d_le = d_lf + (size_t)sub * nl;
-  std::vector<float> lf((size_t)n * nl), le((size_t)n * nl);
-  int rc = MLT_OK;
-  auto run = [&]() -> int {
-    for (int i0 = 0; i0 < n; i0 += sub) {
-      HIP_TRY(ctx, hipMemcpy(d_org, org.data() + (size_t)i0 * cs, plane, hipMemcpyHostToDevice));
-      HIP_TRY(ctx, hipMemcpy(d_pred, pred.data() + (size_t)i0 * cs, plane, hipMemcpyHostToDevice));
-      HIP_TRY(ctx, hipMemcpy(d_poc, poc.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
-      HIP_TRY(ctx, hipMemcpy(d_qp, qp.data() + i0, (size_t)sub * 4, hipMemcpyHostToDevice));
-      int r;
-      if (w2 && w2_from > 0) r = run_network(ctx, st, st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf, nullptr, &st.model_w2, w2_from);
-      else r = run_network(ctx, st, w2 ? st.model_w2 : st.model, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_lf);
-      if (r) return r;
-      if ((r = run_network(ctx, st, st.model_exact, sub, d_org, S, (long)cs, d_pred, S, (long)cs, d_poc, d_qp, d_split, d_le))) return r;
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx, hipMemcpy(lf.data() + (size_t)i0 * nl, d_lf, lgb, hipMemcpyDeviceToHost));
-      HIP_TRY(ctx, hipMemcpy(le.data() + (size_t)i0 * nl, d_le, lgb, hipMemcpyDeviceToHost));
+  int16_t *d_org = nullptr, *d_pred = nullptr;
+  int32_t *d_poc = nullptr, *d_qp = nullptr, *d_split = nullptr;
+  float *d_lg = nullptr;
+  std::vector<float> le, lf;
+  float tail_ratio = 0.f;
+  static constexpr int kSub = 96;
+  CalibSession(mlt_ctx *c, SizeState &s) : ctx(c), st(s) {}
+  ~CalibSession() {
+    if (d) (void)hipFree(d);
+    // the workspace grew to 96 exact CUs (540 MiB at S = 128): release it, the first real call sizes it for its own batch (a max_batch = 1
+    // encoder context would otherwise carry it for life); captured graphs of every size that baked the old workspace in are dropped
+    // with it (a later allocation may return the same address with fewer bytes behind it)
+    (void)hipStreamSynchronize(ctx->stream);
+    release_ws(ctx);
+  }
+  int run(std::vector<float> &out, bool exact, unsigned mask) {
+    const int S = st.size, nl = st.model.n_logits;
+    const long cs = (long)S * S;
+    const bool prof = ctx->profile;
+    ctx->profile = false;
+    int rc = MLT_OK;
+    for (int i0 = 0; i0 < kCalibN && rc == MLT_OK; i0 += kSub) {
+      const int c = kCalibN - i0 < kSub ? kCalibN - i0 : kSub;
+      rc = exact ? run_network(ctx, st, st.model_exact, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl)
+                 : run_network(ctx, st, st.model, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl,
+                               nullptr, mask ? &st.model_w2 : nullptr, mask);
     }
+    ctx->profile = prof;
+    if (rc) return rc;
+    out.resize((size_t)kCalibN * nl);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out.data(), d_lg, out.size() * 4, hipMemcpyDeviceToHost));
     return MLT_OK;
-  };
-  const bool prof = ctx->profile;
-  ctx->profile = false;
-  rc = run();
-  ctx->profile = prof;
-  (void)hipFree(d);
-  // the workspace grew to 16 exact CUs (90 MiB at S = 128): release it, the first real call sizes it for its own batch
-  // (a max_batch = 1 encoder context would otherwise carry it for life)
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->ws) { (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
-  if (rc) return rc;
-  double mx = 0.0;
-  double s2_cls[kCalibClasses] = {0}, s2_head[4] = {0};
-  size_t n_cls[kCalibClasses] = {0}, n_head[4] = {0};
-  for (int i = 0; i < n; ++i) {
-    int lo = 0;
-    for (int h = 0; h < st.model.n_heads; ++h) {
-      for (int k = 0; k < st.model.heads[h].classes; ++k) {
-        const size_t j = (size_t)i * nl + lo + k;
-        const double e = std::fabs((double)lf[j] - (double)le[j]);
-        if (!(e <= mx)) mx = e;  // NaN -> mx = NaN -> fails the test in mlt_load_weights
-        s2_cls[cls[i]] += e * e; ++n_cls[cls[i]];
-        s2_head[h] += e * e; ++n_head[h];
+  }
+  int begin() {
+    const int S = st.size, nl = st.model.n_logits;
+    const size_t cs = (size_t)S * S, plane = cs * 2 * kCalibN;
+    in = &calibration_set(S);
+    HIP_TRY(ctx, hipMalloc((void **)&d, 2 * plane + 3 * (size_t)kCalibN * 4 + (size_t)kCalibN * nl * 4));
+    d_org = (int16_t *)d; d_pred = (int16_t *)(d + plane);
+    d_poc = (int32_t *)(d + 2 * plane); d_qp = d_poc + kCalibN; d_split = d_qp + kCalibN;
+    d_lg = (float *)(d_split + kCalibN);
+    HIP_TRY(ctx, hipMemcpy(d_org, in->org.data(), plane, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_pred, in->pred.data(), plane, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_poc, in->poc.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_qp, in->qp.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
+    return run(le, true, 0);
+  }
+  int price(unsigned mask) {
+    int rc = run(lf, false, mask);
+    if (rc) return rc;
+    const int n = kCalibN, nl = st.model.n_logits;
+    double mx = 0.0, s2_all = 0.0;
+    double s2_cls[kCalibClasses] = {0}, s2_head[4] = {0};
+    size_t n_cls[kCalibClasses] = {0}, n_head[4] = {0};
+    for (int i = 0; i < n; ++i) {
+      int lo = 0;
+      for (int h = 0; h < st.model.n_heads; ++h) {
+        for (int k = 0; k < st.model.heads[h].classes; ++k) {
+          const size_t j = (size_t)i * nl + lo + k;
+          const double e = std::fabs((double)lf[j] - (double)le[j]);
+          if (!(e <= mx)) mx = e;  // NaN -> mx = NaN -> fails the admission test
+          s2_cls[in->cls[i]] += e * e; ++n_cls[in->cls[i]];
+          s2_head[h] += e * e; ++n_head[h];
+          s2_all += e * e;
+        }
+        lo += st.model.heads[h].classes;
       }
-      lo += st.model.heads[h].classes;
     }
+    double worst = 0.0;
+    for (int c = 0; c < kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
+    for (int h = 0; h < st.model.n_heads; ++h) if (n_head[h]) { const double r = std::sqrt(s2_head[h] / (double)n_head[h]); if (!(r <= worst)) worst = r; }
+    const double rms_all = std::sqrt(s2_all / ((double)n * nl));
+    tail_ratio = (float)(rms_all > 0.0 ? mx / rms_all : 0.0);
+    if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
+      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in stages 0x%x): rms per class", st.size, mask);
+      for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
+      std::fprintf(stderr, " | per head");
+      for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
+      std::fprintf(stderr, " | max %.3e = %.1f x rms\n", mx, (double)tail_ratio);
+    }
+    st.calibrated = true;
+    st.calib_rms = (float)worst;
+    st.calib_max = (float)mx;
+    return MLT_OK;
   }
-  double worst = 0.0;
-  for (int c = 0; c < kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
-  for (int h = 0; h < st.model.n_heads; ++h) if (n_head[h]) { const double r = std::sqrt(s2_head[h] / (double)n_head[h]); if (!(r <= worst)) worst = r; }
-  if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
-    std::fprintf(stderr, "mltcnn calibration (size %d, %s): rms per class", S, !w2 ? "single pass" : w2_from > 0 ? "hi+lo weights in layer2 / layer3" : "hi+lo weights");
-    for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
-    std::fprintf(stderr, " | per head");
-    for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
-    std::fprintf(stderr, " | max %.3e\n", mx);
-  }
-  st.calibrated = true;
-  st.calib_rms = (float)worst;
-  st.calib_max = (float)mx;
-  return MLT_OK;
-}
+};
 
 void drop_graphs(mlt_ctx *ctx, int si) {  // a captured kernel chain bakes in weight / workspace pointers
   SingleCu &sg = ctx->single[si];
@@ -934,7 +987,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
   st.loaded = false;
   st.exact = st.want_exact;
-  st.w2 = false; st.w2_from = 0;
+  st.w2 = false; st.w2_mask = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
@@ -952,32 +1005,41 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return fail(rc);
     if (st.calibrate) {
-      if ((rc = calibrate(ctx, st, false))) return fail(rc);
-      // admission: statistical, not a bound -- the worst pooled rms over the content classes / heads of the calibration set, times
-      // 5.5 (a Gaussian tail of 4e-8 per logit), and the largest error seen, with a 25 % margin
-      auto within = [&]() { return 5.5f * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance; };
-      if (!within()) {
-        // single-pass fp16 does not meet the contract for this weight set.  Middle tier: hi+lo WEIGHTS on single fp16 activations
-        // (2 MFMAs per product on the W2 forms of the fused kernels -- a third copy of the weights, on the fast tiling; the weight rounding
-        // is what dominates the fast error), priced the same way; only the 128 model (the small models' error is activation rounding)
+      CalibSession cal(ctx, st);
+      if ((rc = cal.begin())) return fail(rc);
+      if ((rc = cal.price(0))) return fail(rc);
+      // Admission: statistical, not a bound.  (i) 5.5 x the worst pooled rms over the content classes / heads of the calibration set (a
+      // Gaussian tail of 4e-8 per logit); (ii) the largest error seen on the 5040 logits, with a 25 % margin; (iii) round 4 -- a set whose
+      // largest error exceeds 5 x its overall rms on this sample (a Gaussian sample of this size peaks at 3.8) has a heavy tail: it is held
+      // to 6.5 x rms, the worst max / rms ratio the round-3 tail probe (295 k logits per weight set) observed.
+      auto within = [&]() {
+        const float k = cal.tail_ratio > 5.0f ? 6.5f : 5.5f;
+        return k * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance;
+      };
+      static const char *force_mask = tuning_env("MLT_W2_MASK");  // tuning: price exactly this stage mask (even when the single pass would do)
+      if (!within() || force_mask) {
+        // Single-pass fp16 does not meet the contract for this weight set.  Middle tiers: hi+lo WEIGHTS on single fp16 activations (2 MFMAs
+        // per product on the W2 forms of the fused kernels -- a third copy of the weights, on the fast tiling; the weight rounding is what
+        // dominates the fast error), stage by stage: the two models' stages compose freely, the rounding errors of different layers are
+        // independent (their variances add), and on this chip a hi+lo stage costs what its MFMAs cost (the fused W2 kernels run at the
+        // ~1.2 PFLOP/s the power-limited chip sustains) -- so the calibration prices the 15 stage subsets in the order of their measured
+        // cost and keeps the CHEAPEST one that meets the contract.  Only the 128 model (the small models' error is activation rounding).
         const float rms1 = st.calib_rms, max1 = st.calib_max;
-        static const bool no_w2 = std::getenv("MLT_NO_W2") != nullptr;
+        static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
         bool w2_ok = false;
         if (size == 128 && !no_w2) {
           mlt::Model mw;
           if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
           st.model_w2 = std::move(mw);
           if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
-          // first the cheaper "mixed" form -- hi+lo weights for layer2 / layer3 only (the deepest head carries the largest error and half
-          // of the weight-rounding variance sits in those two stages), layer0 / layer1 on the fused single-pass kernels -- then the whole network
-          static const bool no_mixed = std::getenv("MLT_NO_W2_MIXED") != nullptr;
-          if (!no_mixed) {
-            if ((rc = calibrate(ctx, st, true, 2))) return fail(rc);
-            if ((w2_ok = within())) st.w2_from = 2;
-          }
-          if (!w2_ok) {
-            if ((rc = calibrate(ctx, st, true))) return fail(rc);
-            if ((w2_ok = within())) st.w2_from = 0;
+          // added ms per 4096 CUs of a stage in hi+lo weights (measured, round 4: profiles/r04*): layer0 0.88, layer1 0.70, layer2 1.19, layer3 1.20
+          static const unsigned order[15] = {0x2, 0x1, 0x4, 0x8, 0x3, 0x6, 0xA, 0x5, 0x9, 0xC, 0x7, 0xB, 0xE, 0xD, 0xF};
+          for (int k = 0; k < 15 && !w2_ok; ++k) {
+            const unsigned mask = force_mask ? (unsigned)std::strtoul(force_mask, nullptr, 0) & 0xFu : order[k];
+            if (mask == 0) break;
+            if ((rc = cal.price(mask))) return fail(rc);
+            if ((w2_ok = within())) st.w2_mask = mask;
+            if (force_mask) break;
           }
         }
         if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
@@ -1002,7 +1064,9 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->w2 ? (st->w2_from > 0 ? 3 : 2) : 0;
+  out->exact = st->exact ? 1 : st->w2 ? (st->w2_mask != 0xFu ? 3 : 2) : 0;
+  out->w2_stages = st->w2 ? (int32_t)st->w2_mask : 0;
+  out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;
   out->flat_guard = (!st->exact && st->flat_guard) ? 1 : 0;
@@ -1025,10 +1089,12 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   if (!ctx) return MLT_ERR_NOMEM;
   ctx->device = cfg->device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
-  if (cfg->guard_margin > 0.f) ctx->guard_margin = cfg->guard_margin;
   if (cfg->tolerance > 0.f) ctx->tolerance = cfg->tolerance;
-  if (const char *e = std::getenv("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
-  if (const char *e = std::getenv("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
+  // decision guard: two logits that are each within `tolerance` of the reference change their difference by at most 2 x tolerance, so a
+  // top-2 margin of at least that much cannot flip -- everything below it is re-evaluated exactly
+  ctx->guard_margin = cfg->guard_margin > 0.f ? cfg->guard_margin : 2.f * ctx->tolerance;
+  if (const char *e = tuning_env("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
+  if (const char *e = tuning_env("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
   if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_init_error = "hipStreamCreate failed"; delete ctx; return MLT_ERR_HIP; }
   if (hipMalloc((void **)&ctx->zero_page, 65536) != hipSuccess || hipMemset(ctx->zero_page, 0, 65536) != hipSuccess) {
@@ -1043,7 +1109,7 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
     // per context, that this device behaves so -- (ab)using the zero page as the 4-byte result slot, restored afterwards; a device that
     // does not (or MLT_NO_LDS_OOB=1) gets the masked form of the same kernels
     int ok = 0;
-    const bool ran = std::getenv("MLT_NO_LDS_OOB") == nullptr && mlt_probe_lds_oob((int *)ctx->zero_page, ctx->stream) == hipSuccess &&
+    const bool ran = tuning_env("MLT_NO_LDS_OOB") == nullptr && mlt_probe_lds_oob((int *)ctx->zero_page, ctx->stream) == hipSuccess &&
                      hipMemcpyAsync(&ok, ctx->zero_page, sizeof ok, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                      hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (hipMemsetAsync(ctx->zero_page, 0, sizeof ok, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -1308,10 +1374,10 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
     int r = run_guarded_async(ctx, *st, 1, pl, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4), g);  // its 4-byte count D2H lands in h_sc[3]
     return r;
   };
-  static const bool no_graph = std::getenv("MLT_NO_GRAPH") != nullptr || std::getenv("MLT_DEBUG_DUMP_DIR") != nullptr;
+  static const bool no_graph = tuning_env("MLT_NO_GRAPH") != nullptr || tuning_env("MLT_DEBUG_DUMP_DIR") != nullptr;
   bool replayed = false;
   if (!no_graph && !ctx->profile && ctx->own_stream) {
-    if (sg.exec && (sg.ws_at_capture != ctx->ws || sg.stream_at_capture != ctx->stream)) {  // workspace moved: re-capture
+    if (sg.exec && (sg.ws_gen_at_capture != ctx->ws_gen || sg.stream_at_capture != ctx->stream)) {  // workspace re-allocated since: re-capture
       (void)hipGraphExecDestroy(sg.exec); (void)hipGraphDestroy(sg.graph);
       sg.exec = nullptr; sg.graph = nullptr;
     }
@@ -1324,7 +1390,7 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
         hipGraph_t gr = nullptr;
         const hipError_t ce = hipStreamEndCapture(ctx->stream, &gr);
         if (rc == MLT_OK && ce == hipSuccess && gr && hipGraphInstantiate(&sg.exec, gr, nullptr, nullptr, 0) == hipSuccess) {
-          sg.graph = gr; sg.ws_at_capture = ctx->ws; sg.stream_at_capture = ctx->stream;
+          sg.graph = gr; sg.ws_gen_at_capture = ctx->ws_gen; sg.stream_at_capture = ctx->stream;
         } else {
           if (gr) (void)hipGraphDestroy(gr);
           sg.exec = nullptr;

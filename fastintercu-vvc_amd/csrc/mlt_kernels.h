@@ -5,12 +5,19 @@
 
 #define MLT_MAX_HEADS_K 4
 #define MLT_MAX_LOGITS_K 16
-// Flat-content guard statistic (round 3: widened from "exactly constant"): an aligned 4-pixel quad counts when the RANGE (max - min)
+// Flat-content guard statistic (round 3: widened from "exactly constant"): an aligned 4-pixel quad is NEAR-FLAT when the RANGE (max - min)
 // of its four org values AND of its four |org - pred| values -- as the network sees them: uint16 cast, absdiff, clip to 10 bits --
 // is <= MLT_FLAT_RANGE -- +-1 LSB dither, low-contrast texture (amplitude <= 4), every exactly-constant area (sky, letterbox bars,
 // screen content) -- or the four values are LINEAR to within one step (ramps of any slope); per plane either test may hold.  Content
 // on which neighbouring pixels carry correlated fp16 rounding errors that the global pooling cannot average away.
+// Round 4: a quad is EXACTLY FLAT when each plane is constant or exactly linear (range 0, or both second differences 0).  A CU is flagged
+// when >= 1/8 of its quads are exactly flat (identical activations at every pixel: the error mechanism proper, 1.2 - 2.3e-3 measured on
+// constant CUs whatever the weight arithmetic) OR >= 1/2 are near-flat.  With the single 1/8 rule on near-flat quads, 22 % of the CUs of
+// the natural-statistics class (synth.natural_patches: smooth areas + sensor noise) were re-run exactly although their single-pass error
+// is no larger than that of textured CUs (profiles/r04*_natural_probe.txt); the two-level rule flags 3 % of them, and the calibration
+// set carries the content it lets through (a near-flat band over 40-48 % of the quads).
 #define MLT_FLAT_RANGE 8
+#define MLT_FLAT_EXACT_SHIFT 16   // the per-CU statistic packs both counts: near-flat quads in bits 0-15, exactly flat quads in bits 16-31
 
 struct ConvArgs {
   const void *x;      // input  [n][Hin][Hin][CIN]  fp16 NHWC
@@ -149,7 +156,8 @@ struct GuardSelectArgs {
   int32_t *idx;                // [n] out: indices of the selected CUs, ascending
   int32_t *count;              // [1] out
   int n, n_logits, head_off, head_classes;
-  int flat_thr;                // select when flat >= flat_thr (flat != NULL)
+  int flat_thr;                // select when the count of EXACTLY flat quads (flat >> MLT_FLAT_EXACT_SHIFT) >= flat_thr (flat != NULL) ...
+  int near_thr;                // ... or the count of near-flat quads (flat & 0xFFFF) >= near_thr
   float margin;                // select when top1 - top2 of the decision head < margin (logits != NULL, margin > 0)
 };
 struct GuardGatherArgs {

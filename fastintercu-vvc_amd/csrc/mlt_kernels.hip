@@ -150,15 +150,18 @@ __device__ __forceinline__ uint32_t prep_pair(int16_t so, int16_t sp) {
 // quad is "coherent" when its four values span <= MLT_FLAT_RANGE (constant, dither, low contrast) OR are linear to within one step
 // (both second differences <= 1 in magnitude: ramps of any slope -- every pixel of a perfect gradient sees the same local pattern,
 // so its rounding errors are as coherent as a constant area's); the quad counts when BOTH planes are.
-__device__ __forceinline__ bool quad_near_flat(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+// Returns bit 0: near-flat, bit 1: exactly flat (each plane constant or exactly linear; implies near-flat).
+__device__ __forceinline__ int quad_flat_bits(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
   const half2v a = *(half2v *)&w0, b = *(half2v *)&w1, c = *(half2v *)&w2, d = *(half2v *)&w3;
   const half2v mx = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
   const half2v mn = __builtin_elementwise_min(__builtin_elementwise_min(a, b), __builtin_elementwise_min(c, d));
   const half2v r = mx - mn;
   const half2v d1 = (a + c) - (b + b), d2 = (b + d) - (c + c);
   const half2v l = __builtin_elementwise_max(__builtin_elementwise_max(d1, -d1), __builtin_elementwise_max(d2, -d2));
-  const _Float16 R = (_Float16)MLT_FLAT_RANGE, one = (_Float16)1;
-  return (r[0] <= R || l[0] <= one) && (r[1] <= R || l[1] <= one);
+  const _Float16 R = (_Float16)MLT_FLAT_RANGE, one = (_Float16)1, zero = (_Float16)0;
+  const bool near = (r[0] <= R || l[0] <= one) && (r[1] <= R || l[1] <= one);
+  const bool exact = (r[0] == zero || l[0] == zero) && (r[1] == zero || l[1] == zero);
+  return (near ? 1 : 0) | (exact ? 2 : 0);
 }
 
 // ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace mlt {
@@ -125,7 +126,8 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
       hi_slot = q;
       (&hi_slot)[pc.plane_halves] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
     } else {
-      const uint16_t q = f32_to_f16((float)(exact - err));
+      static const bool plain = [] { const char *t = std::getenv("MLT_TUNING"), *e = std::getenv("MLT_PLAIN_ROUNDING"); return t && t[0] == '1' && e; }();  // experiment: no tap diffusion
+      const uint16_t q = f32_to_f16((float)(plain ? exact : exact - err));
       err += (double)f16_to_f32(q) - exact;
       hi_slot = q;
     }
@@ -175,7 +177,8 @@ static void pack_stem5(PackedConv &pc, const float *ws, const float *w1, const s
       pc.w[idx] = q;
       pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
     } else {
-      const double tgt = err ? exact - *err : exact;
+      static const bool plain = [] { const char *t = std::getenv("MLT_TUNING"), *e = std::getenv("MLT_PLAIN_ROUNDING"); return t && t[0] == '1' && e; }();
+      const double tgt = (err && !plain) ? exact - *err : exact;
       const uint16_t q = f32_to_f16((float)tgt);
       if (err) *err += (double)f16_to_f32(q) - exact;
       pc.w[idx] = q;
@@ -234,7 +237,8 @@ static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const 
       pc.w[pc.plane_halves + idx] = f32_to_f16((float)(exact - (double)f16_to_f32(q)));
       return;
     }
-    const double tgt = err ? exact - *err : exact;
+    static const bool plain = [] { const char *t = std::getenv("MLT_TUNING"), *e = std::getenv("MLT_PLAIN_ROUNDING"); return t && t[0] == '1' && e; }();
+    const double tgt = (err && !plain) ? exact - *err : exact;
     const uint16_t q = f32_to_f16((float)tgt);
     if (err) *err += (double)f16_to_f32(q) - exact;
     pc.w[idx] = q;

@@ -166,8 +166,67 @@ KIND_RAMP = 9              # smooth horizontal / diagonal luma ramps, pred = the
 KIND_DITHER = 10           # constant +- 1 LSB dither in both planes
 KIND_LOW_CONTRAST = 11     # texture of amplitude <= 4 on a constant base, pred = org + noise[-2,2]
 KIND_FLAT_ZERO_RESI = 12   # constant org and pred == org (zero residual on flat content)
+KIND_NATURAL = 13          # natural-image statistics (round 4): 1/f amplitude spectrum, per-patch contrast, sensor noise; pred = the
+                           # same scene displaced by a small motion vector, low-passed (interpolation + quantised reference) + noise
+KIND_PARTIAL_NEAR_FLAT = 14  # texture with a NEAR-flat band (+-1 LSB dither / amplitude-4 texture on constants, never exactly constant) over
+                             # 40-48 % of the quads: just under the guard's threshold for near-flat content (1/2)
 KIND_NAMES = {0: "texture", 1: "uniform", 2: "zero_resi", 3: "saturated", 4: "flat", 5: "out_of_range", 6: "partial_flat",
-              7: "org_flat_pred_tex", 8: "org_tex_pred_flat", 9: "ramp", 10: "dither", 11: "low_contrast", 12: "flat_zero_resi"}
+              7: "org_flat_pred_tex", 8: "org_tex_pred_flat", 9: "ramp", 10: "dither", 11: "low_contrast", 12: "flat_zero_resi",
+              13: "natural", 14: "partial_near_flat"}
+
+
+def natural_patches(size: int, n: int, input_seed: int, first: int = 0):
+    """n (org, pred) pairs with natural-image statistics -- the content class the flat-content guard's FLAG RATE is quoted on.
+
+    org : a (size + 8)^2 random-phase field with a 1/f amplitude spectrum (power 1/f^2, the classic natural-image law), scaled to a
+          per-patch standard deviation drawn log-uniformly from 6 ... 160 ten-bit steps (sky / out-of-focus background ... foliage),
+          around a mean of 120 ... 900, + sensor noise of +-1 step, clipped to 10 bits; the centre size x size window is the CU.
+    pred: the same field displaced by an integer motion vector in [-2, 2]^2 (what a merge / skip candidate points at), smoothed by
+          the [1 2 1]^2 / 16 kernel with probability 1/2 (sub-pel interpolation + a quantised reference), + noise of amplitude
+          0 ... 6 steps (the reference picture's coding error).
+    Deterministic in (input_seed, first + i); float FFTs, so reproducible on one numpy build (probes / bench, not fixtures)."""
+    m = size + 8
+    org = np.empty((n, size, size), np.int16)
+    pred = np.empty((n, size, size), np.int16)
+    fy = np.fft.fftfreq(m)[:, None]
+    fx = np.fft.rfftfreq(m)[None, :]
+    f = np.sqrt(fy * fy + fx * fx)
+    f[0, 0] = 1.0
+    amp = 1.0 / f
+    amp[0, 0] = 0.0
+    step = 128
+    for i0 in range(0, n, step):
+        c = min(step, n - i0)
+        base = (first + i0) * m * (m // 2 + 1)
+        cnt = c * m * (m // 2 + 1)
+        ph = uniform(input_seed, "nat/phase", cnt, base).reshape(c, m, m // 2 + 1) * (2.0 * math.pi)
+        mag = np.sqrt(-2.0 * np.log(1.0 - uniform(input_seed, "nat/mag", cnt, base).reshape(c, m, m // 2 + 1)))
+        field = np.fft.irfft2(amp[None] * mag * np.exp(1j * ph), s=(m, m))
+        field -= field.mean(axis=(1, 2), keepdims=True)
+        field /= field.std(axis=(1, 2), keepdims=True) + 1e-12
+        u = uniform(input_seed, "nat/par", c * 4, (first + i0) * 4).reshape(c, 4)
+        sd = 6.0 * np.exp(u[:, 0] * math.log(160.0 / 6.0))
+        mean = 120.0 + 780.0 * u[:, 1]
+        scene = mean[:, None, None] + sd[:, None, None] * field
+        sens = randint(input_seed, "nat/sens", c * m * m, -1, 1, (first + i0) * m * m).reshape(c, m, m)
+        o_full = np.clip(np.rint(scene) + sens, 0, 1023)
+        mv = randint(input_seed, "nat/mv", c * 2, -2, 2, (first + i0) * 2).reshape(c, 2)
+        namp = (u[:, 2] * 7.0).astype(np.int64)  # 0 ... 6
+        blur = u[:, 3] < 0.5
+        pn = raw_u64(input_seed, "nat/pn", c * size * size, (first + i0) * size * size).reshape(c, size, size)
+        for k in range(c):
+            ref = o_full[k]
+            if blur[k]:
+                r = ref.copy()
+                r[1:-1, 1:-1] = (ref[:-2, :-2] + 2 * ref[:-2, 1:-1] + ref[:-2, 2:] + 2 * ref[1:-1, :-2] + 4 * ref[1:-1, 1:-1] + 2 * ref[1:-1, 2:]
+                                 + ref[2:, :-2] + 2 * ref[2:, 1:-1] + ref[2:, 2:] + 8) // 16
+                ref = r
+            y0, x0 = 4 + int(mv[k, 0]), 4 + int(mv[k, 1])
+            a = int(namp[k])
+            noise = (pn[k] % np.uint64(2 * a + 1)).astype(np.int64) - a
+            org[i0 + k] = o_full[k, 4:4 + size, 4:4 + size].astype(np.int16)
+            pred[i0 + k] = np.clip(ref[y0:y0 + size, x0:x0 + size] + noise, 0, 1023).astype(np.int16)
+    return org, pred
 
 
 def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, first: int = 0):
@@ -250,6 +309,23 @@ def make_patches(size: int, n: int, input_seed: int, kind: int = KIND_TEXTURE, f
         elif kind == KIND_FLAT_ZERO_RESI:
             o = np.full((size, size), int(randint(input_seed, tag + "/o", 1, 0, 1023)[0]), dtype=np.int64)
             p = o.copy()
+        elif kind == KIND_PARTIAL_NEAR_FLAT:
+            nb = max(size // 16, 1)
+            base = randint(input_seed, tag + "/base", nb * nb, 64, 959).reshape(nb, nb)
+            base = np.kron(base, np.ones((size // nb, size // nb), dtype=np.int64))
+            o = np.clip(base + randint(input_seed, tag + "/tex", px, -48, 48).reshape(size, size), 0, 1023)
+            p = np.clip(o + randint(input_seed, tag + "/noise", px, -40, 40).reshape(size, size), 0, 1023)
+            hh = max((size * (40 + 4 * (idx % 3))) // 100, 1)   # 40 / 44 / 48 % of the rows
+            r0 = int(randint(input_seed, tag + "/r0", 1, 0, size - hh)[0])
+            co = int(randint(input_seed, tag + "/co", 1, 8, 1015)[0])
+            cp = int(randint(input_seed, tag + "/cp", 1, 8, 1015)[0])
+            amp = 1 if idx % 2 == 0 else 4   # dither / low contrast
+            o[r0:r0 + hh, :] = co + randint(input_seed, tag + "/do", hh * size, -amp, amp).reshape(hh, size)
+            p[r0:r0 + hh, :] = cp + randint(input_seed, tag + "/dp", hh * size, -amp, amp).reshape(hh, size)
+            # (not a single exactly-constant quad: keep the band clear of the guard's 1/8 rule for exactly flat content)
+        elif kind == KIND_NATURAL:
+            oo, pp = natural_patches(size, 1, input_seed, idx)
+            o, p = oo[0].astype(np.int64), pp[0].astype(np.int64)
         else:
             raise ValueError(kind)
         org[i] = o.astype(np.int16)
@@ -286,3 +362,41 @@ def make_patches_bulk(size: int, n: int, input_seed: int, first: int = 0):
         org[i0:i0 + c] = o
         pred[i0:i0 + c] = np.clip(o + fast("bulk/noise", c * px, -40, 40, f * px).reshape(c, size, size), 0, 1023)
     return org, pred
+
+
+def make_mix_bulk(size: int, n: int, input_seed: int, flat_frac: float = 0.0, natural: bool = False, first: int = 0):
+    """Bench batches beyond the plain texture workload: a fraction `flat_frac` of the CUs (every k-th, evenly spread) replaced by the
+    content the flat-content guard re-evaluates exactly -- constant, +-1 LSB dither, ramps, low contrast, in turn -- and / or the
+    natural-statistics class instead of the texture class for the rest.  Returns (org, pred, is_flat[n])."""
+    org, pred = (natural_patches(size, n, input_seed, first) if natural else make_patches_bulk(size, n, input_seed, first))
+    is_flat = np.zeros(n, bool)
+    if flat_frac > 0:
+        kinds = (KIND_FLAT, KIND_DITHER, KIND_RAMP, KIND_LOW_CONTRAST)
+        pos = np.unique(np.floor(np.arange(int(round(n * flat_frac))) / max(flat_frac, 1e-9)).astype(np.int64))
+        pos = pos[pos < n]
+        for j, i in enumerate(pos):
+            o, p = make_patches(size, 1, input_seed ^ 0x5A5A, kinds[j % 4], first + int(i))
+            org[i], pred[i] = o[0], p[0]
+            is_flat[i] = True
+    return org, pred, is_flat
+
+
+def flat_quad_fraction(org: np.ndarray, pred: np.ndarray, flat_range: int = 8, return_exact: bool = False):
+    """Host restatement of the flat-content guard's statistic (csrc/mlt_kernels.hip: quad_near_flat): per CU, the fraction of aligned
+    4-pixel quads that are coherent in BOTH planes the network sees (org clipped to 10 bits, |org - pred| clipped) -- range <= flat_range
+    or linear to within one step.  The guard flags a CU when the fraction reaches 1/8."""
+    o = np.clip(org.astype(np.uint16).astype(np.int64), 0, 1023)
+    r = np.clip(np.abs(org.astype(np.uint16).astype(np.int64) - pred.astype(np.uint16).astype(np.int64)), 0, 1023)
+    n, S, _ = o.shape
+    res = np.ones((n, S, S // 4), bool)
+    exact = np.ones((n, S, S // 4), bool)
+    for a in (o, r):
+        q = a.reshape(n, S, S // 4, 4)
+        rng = q.max(-1) - q.min(-1)
+        d1 = np.abs(q[..., 0] + q[..., 2] - 2 * q[..., 1])
+        d2 = np.abs(q[..., 1] + q[..., 3] - 2 * q[..., 2])
+        res &= (rng <= flat_range) | (np.maximum(d1, d2) <= 1)
+        exact &= (rng == 0) | (np.maximum(d1, d2) == 0)
+    if return_exact:
+        return res.reshape(n, -1).mean(1), exact.reshape(n, -1).mean(1)
+    return res.reshape(n, -1).mean(1)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MLT_ABI_VERSION 2
+#define MLT_ABI_VERSION 3
 
 enum {
   MLT_OK = 0,
@@ -49,12 +49,13 @@ enum {
  * exact), 64/32/16 -> exact (few pixels per map, so fp16 rounding is not averaged away by the global pooling, and these
  * models are 5-65x cheaper).  Sizes that run the fast arithmetic are protected by two device-side guards, applied on
  * EVERY entry point (single, batch, device-pointer, deferred):
- *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are COHERENT -- the four org values and the four
- *                            |org - pred| values each span <= 8 (10-bit steps) or are linear to within one step: constant areas,
- *                            +-1 LSB dither, low-contrast texture, ramps -- are re-evaluated with the exact arithmetic (their
- *                            fp16 rounding errors are coherent, the global pooling does not average them away);
- *   decision guard (opt-in): CUs whose decision-head top-2 margin is below guard_margin are re-evaluated too, so the
- *                            split mode handed to EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
+ *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are EXACTLY FLAT (org and |org - pred| each constant or
+ *                            exactly linear over the quad) or >= 1/2 are NEAR-FLAT (each spans <= 8 ten-bit steps or is linear to
+ *                            within one step: +-1 LSB dither, low-contrast texture, ramps) are re-evaluated with the exact
+ *                            arithmetic (their fp16 rounding errors are coherent, the global pooling does not average them away);
+ *   decision guard (opt-in in this struct; ON by default in host/mlt_split_predictor.hpp, the encoder's path): CUs whose
+ *                            decision-head top-2 margin is below guard_margin (default 2 x tolerance) are re-evaluated too, so
+ *                            the split mode handed to EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
  * Both cost a second (exact) copy of the weights on the device (11 MB). */
 #define MLT_FLAG_EXACT_128 0x1u
 #define MLT_FLAG_FAST_SMALL 0x2u       /* single-pass fp16 for 64/32/16 (measurement only: NO seeded weight set meets 1e-3 with it --
@@ -76,7 +77,9 @@ typedef struct mlt_config {
                              element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
   int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
   uint32_t flags;         /* MLT_FLAG_* bits, 0 = defaults */
-  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 0.02 */
+  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 2 x tolerance: two logits
+                             that are each within `tolerance` of the reference move their difference by at most that much, so a
+                             larger margin cannot flip and everything below it is re-evaluated exactly */
   float tolerance;        /* |dlogit| contract the fast arithmetic is calibrated against at load time; <= 0 => 1e-3
                              (BASELINE.json north_star) */
   uint32_t reserved;      /* 0 */
@@ -89,26 +92,29 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out);
 
 /* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
  * blob arrives over RCCL broadcast instead of from weights_dir.  A size configured for the fast arithmetic is
- * CALIBRATED here: 96 seeded synthetic CUs in five content classes the flat guard does not catch (texture, i.i.d. uniform,
- * constant org / textured pred, textured org / constant pred, a constant band just under the guard's threshold) run
+ * CALIBRATED here: 560 seeded synthetic CUs in six content classes the flat guard does not catch (texture, i.i.d. uniform,
+ * constant org / textured pred, textured org / constant pred, a constant band and a near-flat band just under the guard's two thresholds) run
  * through the fast and the exact arithmetic on the device; the fast arithmetic is kept only if
- * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| <= 0.75 x tolerance;
+ * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| (over 5040 logits) <=
+ * 0.75 x tolerance -- a set whose largest error exceeds 5 x its overall rms (heavy tail) is held to 6.5 x rms instead;
  * otherwise the 128 model tries the middle tiers the same way -- fp16 (hi, lo) pairs for the WEIGHTS only, 2 MFMAs per
- * product: first for layer2 / layer3 alone (the deepest head carries the largest error; layer0 / layer1 stay on the fused
- * single-pass kernels), then for the whole network -- and a size that meets the contract with none of them runs exact
- * (mlt_arithmetic reports the outcome).  The
+ * product on the W2 forms of the fused kernels, in a SUBSET of the four stages: the 15 subsets are priced in the order of
+ * their measured cost and the cheapest one that meets the contract is kept (mlt_arith_info.w2_stages) -- and a size that
+ * meets the contract with none of them runs exact (mlt_arithmetic reports the outcome).  The
  * admission is STATISTICAL (synthetic content, Gaussian-tail factor), not a bound: "within 1e-3" is calibrated, not proven. */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 
 /* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
 typedef struct mlt_arith_info {
-  int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations;
-                             3: (hi, lo) weights in layer2 / layer3 only, layer0 / layer1 single pass on the fused kernels */
+  int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations in
+                             every stage; 3: (hi, lo) weights in SOME stages (w2_stages), single pass in the others */
   int32_t calibrated;     /* 1: the calibration ran for this size */
   float calib_rms, calib_max; /* |dlogit| of the chosen non-exact tier (or of the fast one if exact was chosen) vs exact over the calibration CUs:
                                  worst rms pooled per content class / per head, and the overall maximum */
   int32_t flat_guard, decision_guard;
   uint64_t guard_reruns;  /* CUs re-evaluated by the guards since init */
+  int32_t w2_stages;      /* ABI 3: bit s set = layer s (0..3) runs (hi, lo) weights; 0 for the fast and the exact arithmetic */
+  float guard_margin;     /* ABI 3: the decision guard's threshold in effect for this size (0 when the guard is off) */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 

@@ -30,7 +30,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 301
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 res = {}
 for val in (None, "1"):
-    env = dict(os.environ)
+    env = dict(os.environ, MLT_TUNING="1")
     if val:
         env[var] = val
     out = f"/tmp/ab_{var}_{val}.npy"

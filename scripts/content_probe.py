@@ -4,6 +4,7 @@ weak #1: near-threshold partial-flat, one-plane-flat, ramps, dither, low contras
   default  : calibration + guards (what ships)
   nocal    : fast arithmetic forced, guards on (MLT_FLAG_NO_CALIBRATION)
   raw      : fast arithmetic, no guards (measurement only)
+  tier, no guard : whatever tier the calibration picks, flat guard off (with MLT_TUNING=1 MLT_W2_MASK=15: hi+lo weights in every stage)
 usage: python scripts/content_probe.py [--seeds 10,11] [--n 8] [--kinds 0,4,6,...]"""
 import argparse
 import os
@@ -29,7 +30,8 @@ def main():
     S = a.size
     arch = pkg.synth.arch_for_size(S)
     F = pkg.capi
-    modes = [("default", 0), ("nocal", F.FLAG_NO_CALIBRATION), ("raw", F.FLAG_NO_CALIBRATION | F.FLAG_NO_FLAT_GUARD)]
+    modes = [("default", 0), ("nocal", F.FLAG_NO_CALIBRATION), ("raw", F.FLAG_NO_CALIBRATION | F.FLAG_NO_FLAT_GUARD),
+             ("tier, no guard", F.FLAG_NO_FLAT_GUARD)]  # the calibrated tier (MLT_TUNING=1 MLT_W2_MASK=15: hi+lo weights everywhere) without the flat guard
     if S != 128:
         modes = [("default", 0), ("fast_small", F.FLAG_FAST_SMALL)]
     for seed in [int(v) for v in a.seeds.split(",")]:

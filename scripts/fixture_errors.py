@@ -43,7 +43,7 @@ def main():
         for name in dump:
             d = os.path.join(args.out, name)
             os.makedirs(d, exist_ok=True)
-            env = dict(os.environ, MLT_DEBUG_DUMP_DIR=d, MLT_DUMP_CASE=name)
+            env = dict(os.environ, MLT_TUNING="1", MLT_DEBUG_DUMP_DIR=d, MLT_DUMP_CASE=name)
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--flags", "--size", str(args.size)], env=env)
     if os.environ.get("MLT_DUMP_CASE"):
         case = [c for c in golden["cases"] if c["name"] == os.environ["MLT_DUMP_CASE"]][0]

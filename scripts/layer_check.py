@@ -20,6 +20,7 @@ def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     dump = tempfile.mkdtemp(prefix="mltdump_")
+    os.environ["MLT_TUNING"] = "1"
     os.environ["MLT_DEBUG_DUMP_DIR"] = dump
     os.environ["MLT_NO_BLOCK_FUSION"] = "1"  # one launch (and one dumped tensor) per conv: the fused layer0 kernels keep t / sc on chip
     pkg = mltcnn_pkg.load()

@@ -10,6 +10,7 @@ import mltcnn_pkg  # noqa: E402
 pkg = mltcnn_pkg.load()
 out = os.path.join(os.path.dirname(pkg.build.__file__), "_variants", "lib_phase.so")
 pkg.build.build_lib(force=True, defines=["MLT_PHASE_TIMING=1"], out=out)
+os.environ["MLT_TUNING"] = "1"
 os.environ["MLT_LIB_PATH"] = out
 import torch  # noqa: E402
 

@@ -3,7 +3,7 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for mode, steps, warm in (("default", 10, 3), ("spin", 10, 3), ("block", 10, 3), ("default", 10, 20), ("spin", 10, 20), ("default", 50, 5), ("spin", 50, 5), ("noguard", 10, 3), ("noguard", 50, 5)):
-    env = dict(os.environ)
+    env = dict(os.environ, MLT_TUNING="1")
     for k in ("MLT_GUARD_SPIN_WAIT", "MLT_GUARD_BLOCKING_WAIT"):
         env.pop(k, None)
     if mode == "spin":

@@ -32,7 +32,7 @@ def main():
             list(ex.map(one, VARIANTS.items()))
     else:
         for name in VARIANTS:
-            env = dict(os.environ, MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
+            env = dict(os.environ, MLT_TUNING="1", MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")],
                                  env=env, capture_output=True, text=True).stdout
             line = [l for l in out.splitlines() if l.startswith("{")]

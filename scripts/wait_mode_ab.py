@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for mode in ("default", "spin", "block") * 2:
-    env = dict(os.environ)
+    env = dict(os.environ, MLT_TUNING="1")
     env.pop("MLT_GUARD_SPIN_WAIT", None)
     env.pop("MLT_GUARD_BLOCKING_WAIT", None)
     if mode == "spin":

@@ -492,6 +492,7 @@ def test_padding_from_beyond_the_lds_equals_the_masked_kernels(gpu, monkeypatch)
     m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)
     s0, l0 = m.predict_batch(org, pred, poc, qp)
     m.close()
+    monkeypatch.setenv("MLT_TUNING", "1")  # the library's switches are honoured only with it (an encoder's environment cannot flip them by accident)
     monkeypatch.setenv("MLT_NO_LDS_OOB", "1")
     mm = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)
     s1, l1 = mm.predict_batch(org, pred, poc, qp)
@@ -590,6 +591,7 @@ def test_full_batch_4096_properties(gpu, size):
     m.synchronize()
     assert np.array_equal(d_logits.cpu().numpy(), l0) and np.array_equal(d_split.cpu().numpy(), s0)
     m.close()
+    os.environ["MLT_TUNING"] = "1"
     os.environ["MLT_CHUNK"] = "1000"  # ragged chunks: 1000,1000,1000,1000,96
     try:
         mc = _ctx(pkg, size, blob)
@@ -600,6 +602,7 @@ def test_full_batch_4096_properties(gpu, size):
         mc.close()
     finally:
         del os.environ["MLT_CHUNK"]
+        del os.environ["MLT_TUNING"]
     assert np.array_equal(lc, l0) and np.array_equal(sc, s0), "result depends on chunking"
     assert np.array_equal(d_logits.cpu().numpy(), l0) and np.array_equal(d_split.cpu().numpy(), s0), "device entry depends on chunking"
     idx = np.sort(np.random.RandomState(11).choice(n, 24, replace=False))
@@ -709,6 +712,7 @@ def test_device_entry_point_chunk_loop(gpu, monkeypatch):
     ref = _ctx(pkg, size, blob)
     s_ref, l_ref = ref.predict_batch(org, pred, poc, qp)
     ref.close()
+    monkeypatch.setenv("MLT_TUNING", "1")
     monkeypatch.setenv("MLT_CHUNK", "96")
     m = _ctx(pkg, size, blob, max_batch=n)
     dev = torch.device("cuda", 0)
