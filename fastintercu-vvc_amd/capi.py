@@ -22,7 +22,7 @@ FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
 FLAG_DECISION_GUARD = 0x4  # CUs with a near-tie on the decision head are re-evaluated with the exact arithmetic
 FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (measurement only)
 FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
-EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
+EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
 
@@ -30,7 +30,8 @@ EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_load_weights", "mlt_arithmetic", 
 class MltConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("weights_dir", C.c_char_p),
                 ("size_mask", C.c_uint32), ("head_index", C.c_int32 * 4), ("max_batch", C.c_int32),
-                ("flags", C.c_uint32), ("guard_margin", C.c_float), ("tolerance", C.c_float), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("guard_margin", C.c_float), ("tolerance", C.c_float), ("reserved", C.c_uint32),
+                ("n_devices", C.c_int32), ("devices", C.c_int32 * 8)]
 
 
 class MltArithInfo(C.Structure):
@@ -73,6 +74,9 @@ def load_library():
     vp, i32 = C.c_void_p, C.c_int
     lib.mlt_abi_version.restype = i32
     lib.mlt_init.argtypes = [C.POINTER(MltConfig), C.POINTER(vp)]
+    lib.mlt_num_devices.argtypes = [vp]
+    lib.mlt_device_ctx.argtypes = [vp, i32]
+    lib.mlt_device_ctx.restype = vp
     lib.mlt_load_weights.argtypes = [vp, i32, vp, C.c_size_t]
     lib.mlt_arithmetic.argtypes = [vp, i32, C.POINTER(MltArithInfo)]
     lib.mlt_predict.argtypes = [vp, vp, i32, vp, i32, i32, C.c_int32, C.c_int32, vp, vp]
@@ -102,11 +106,16 @@ class MltCnn:
 
     def __init__(self, device: int = 0, sizes=(128,), weights_dir: str | None = None, blobs: dict | None = None,
                  head_index: dict | None = None, max_batch: int = 4096, flags: int = 0, guard_margin: float = 0.0,
-                 tolerance: float = 0.0):
+                 tolerance: float = 0.0, devices=None):
+        """devices: list of HIP ordinals -> ONE context serving several GPUs (mlt_config.n_devices / devices[]); None: `device`."""
         self._lib = load_library()
         cfg = MltConfig()
         cfg.struct_size = C.sizeof(MltConfig)
         cfg.device = device
+        if devices:
+            cfg.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = d
         cfg.weights_dir = weights_dir.encode() if weights_dir else None
         cfg.size_mask = sum(SIZE_BITS[s] for s in sizes)
         for i, s in enumerate((128, 64, 32, 16)):
@@ -146,6 +155,19 @@ class MltCnn:
         """Arithmetic the size runs after loading (fast / exact), what the calibration measured, guard activity."""
         info = MltArithInfo()
         self._check(self._lib.mlt_arithmetic(self._h, size, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_}
+
+    def num_devices(self) -> int:
+        return self._lib.mlt_num_devices(self._h)
+
+    def arithmetic_of_device(self, index: int, size: int) -> dict:
+        info = MltArithInfo()
+        h = self._lib.mlt_device_ctx(self._h, index)
+        if not h:
+            raise MltError(1, "no such device index")
+        rc = self._lib.mlt_arithmetic(h, size, C.byref(info))
+        if rc != MLT_OK:
+            raise MltError(rc, self._lib.mlt_last_error(h).decode())
         return {k: getattr(info, k) for k, _ in MltArithInfo._fields_}
 
     def num_logits(self, size: int) -> int:

@@ -58,7 +58,11 @@ struct SizeState {
   bool calibrated = false;
   float calib_rms = 0.f, calib_max = 0.f;
   uint64_t reruns = 0;         // CUs re-evaluated by the guards
-  double guard_us_per_cu = 0.0; // running estimate of (enqueue -> flagged-CU count on the host) per CU of a batch (run_checked's sleep)
+  // run_checked's sleep: measured duration (enqueue -> flagged-CU count on the host) of a guarded chunk, per power-of-two bucket of the chunk
+  // size (a 4-CU tail costs ~50 us per CU, a 4096-CU chunk ~1.2: ONE per-CU figure for all sizes made a tail's measurement inflate the
+  // next full chunk's sleep 20-fold); guard_n[b] = the chunk size guard_us[b] was measured on; 0: unknown -> poll
+  double guard_us[16] = {0};
+  int guard_n[16] = {0};
   int size = 0, head_index = 0;
   mlt::Model model;
   mlt::Model model_exact;      // fast sizes: exact-arithmetic copy the guards re-evaluate flagged CUs with
@@ -103,6 +107,12 @@ struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector
 }  // namespace
 
 struct mlt_ctx {
+  // multi-device context (mlt_config.n_devices > 1): this object is the context of devices[0]; peers[i] is the full context of
+  // devices[i + 1].  Host-pointer entry points shard over all of them (contiguous ranges, one host thread per peer), mlt_submit deals
+  // CUs round-robin (the ticket's top byte is the device index); device-pointer calls, streams and profiles address ONE device
+  // (mlt_device_ctx).  A peer never has peers of its own.
+  std::vector<mlt_ctx *> peers;
+  unsigned rr = 0;  // next device of mlt_submit
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -761,7 +771,11 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   if (wait_mode == 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_guard));
   else {
     const auto t0 = std::chrono::steady_clock::now();
-    const double expect_us = st.guard_us_per_cu * (double)n;
+    // Only chunks of >= 512 CUs are worth sleeping for (shorter ones are through in well under a millisecond: poll), and only on an
+    // estimate measured on a chunk of the same power-of-two bucket, scaled by the ratio of the sizes.
+    int b = 0;
+    while (b < 15 && (2 << b) <= n) ++b;
+    const double expect_us = (n >= 512 && st.guard_n[b] > 0) ? st.guard_us[b] * (double)n / (double)st.guard_n[b] : 0.0;
     const bool slept = wait_mode == 0 && expect_us > 400.0;
     if (slept) std::this_thread::sleep_for(std::chrono::microseconds((long)(expect_us - 250.0)));
     hipError_t e = hipEventQuery(ctx->ev_guard);
@@ -773,12 +787,16 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
       e = hipEventQuery(ctx->ev_guard);
     }
     HIP_TRY(ctx, e);
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (double)n;
-    // The estimate must never get stuck above the truth (oversleeping costs GPU time, polling only host time): a wake-up that found the
-    // batch finished shrinks it by 15 % -- so a one-off slow call (first launch: module load, workspace allocation) is forgotten within a
-    // few calls -- and a measured duration (we polled, so `us` is exact) replaces it half-way, or at once when it is shorter.
-    if (overslept) st.guard_us_per_cu *= 0.85;
-    else st.guard_us_per_cu = (st.guard_us_per_cu <= 0.0 || us < st.guard_us_per_cu) ? us : 0.5 * (st.guard_us_per_cu + us);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    // The estimate must never stay above the truth (oversleeping costs GPU time, polling only host time): a wake-up that found the batch
+    // finished FORGETS the bucket's estimate -- the next chunk of that size is polled from the start and measured exactly -- and a
+    // measured duration (we polled, so `us` is exact) replaces the estimate at once when it is shorter, half-way when it is longer.
+    if (overslept) { st.guard_n[b] = 0; st.guard_us[b] = 0.0; }
+    else if (n >= 512) {
+      const double scaled = st.guard_n[b] > 0 ? st.guard_us[b] * (double)n / (double)st.guard_n[b] : 0.0;
+      st.guard_us[b] = (st.guard_n[b] == 0 || us < scaled) ? us : 0.5 * (scaled + us);
+      st.guard_n[b] = n;
+    }
   }
   const int k = *g.h_count;
   if (k < 0 || k > n) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
@@ -969,6 +987,10 @@ const char *mlt_last_error(const mlt_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (!ctx || !blob) return MLT_ERR_ARG;
+  for (mlt_ctx *p : ctx->peers) {  // one host blob, uploaded (and calibrated) once per device
+    const int rc = mlt_load_weights(p, size, blob, bytes);
+    if (rc) { ctx->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
+  }
   const int si = size_index(size);
   if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
   SizeState &st = ctx->sz[si];
@@ -1075,19 +1097,21 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   return MLT_OK;
 }
 
-int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
-  std::lock_guard<std::mutex> lock(g_mutex);
-  if (!cfg || !out || cfg->struct_size != sizeof(mlt_config)) { g_init_error = "bad mlt_config"; return MLT_ERR_ARG; }
+#pragma GCC visibility pop
+}  // extern "C"
+namespace {
+// one context on one device (cfg->device is ignored: `device` decides)
+int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
   *out = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
     g_init_error = "no usable HIP device (this library has no CPU fallback)";
     return MLT_ERR_NO_DEVICE;
   }
-  if (hipSetDevice(cfg->device) != hipSuccess) { g_init_error = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess) { g_init_error = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   mlt_ctx *ctx = new (std::nothrow) mlt_ctx();
   if (!ctx) return MLT_ERR_NOMEM;
-  ctx->device = cfg->device;
+  ctx->device = device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
   if (cfg->tolerance > 0.f) ctx->tolerance = cfg->tolerance;
   // decision guard: two logits that are each within `tolerance` of the reference change their difference by at most 2 x tolerance, so a
@@ -1154,8 +1178,44 @@ int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   return MLT_OK;
 }
 
+// contiguous shard of n items for device g of G (fastintercu-vvc_amd/shard.py: shard_bounds)
+inline int shard_lo(int n, int g, int G) { return (int)(((long long)n * g) / G); }
+inline mlt_ctx *device_of(mlt_ctx *ctx, int i) { return i == 0 ? ctx : ctx->peers[(size_t)i - 1]; }
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  // ABI 2 callers pass the 56-byte struct (no device list): accepted, one device
+  if (!cfg || !out || (cfg->struct_size != sizeof(mlt_config) && cfg->struct_size != MLT_CONFIG_SIZE_ABI2)) { g_init_error = "bad mlt_config"; return MLT_ERR_ARG; }
+  *out = nullptr;
+  const int nd = cfg->struct_size == sizeof(mlt_config) ? cfg->n_devices : 0;
+  if (nd < 0 || nd > MLT_MAX_DEVICES) { g_init_error = "bad mlt_config.n_devices"; return MLT_ERR_ARG; }
+  mlt_ctx *ctx = nullptr;
+  int rc = init_one(cfg, nd > 0 ? cfg->devices[0] : cfg->device, &ctx);
+  if (rc) return rc;
+  for (int i = 1; i < nd; ++i) {  // one full context per further device; weights_dir is read (and calibrated) by each
+    mlt_ctx *peer = nullptr;
+    if ((rc = init_one(cfg, cfg->devices[i], &peer))) { mlt_shutdown(ctx); return rc; }
+    ctx->peers.push_back(peer);
+  }
+  *out = ctx;
+  return MLT_OK;
+}
+
+int mlt_num_devices(const mlt_ctx *ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index) {
+  if (!ctx || index < 0 || index > (int)ctx->peers.size()) return nullptr;
+  return device_of(ctx, index);
+}
+
 void mlt_shutdown(mlt_ctx *ctx) {
   if (!ctx) return;
+  for (mlt_ctx *p : ctx->peers) mlt_shutdown(p);
+  ctx->peers.clear();
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->prof)
@@ -1205,6 +1265,11 @@ int mlt_set_stream(mlt_ctx *ctx, void *hip_stream) {
 
 int mlt_synchronize(mlt_ctx *ctx) {
   if (!ctx) return MLT_ERR_ARG;
+  for (mlt_ctx *p : ctx->peers) {
+    const int rc = mlt_synchronize(p);
+    if (rc) { ctx->err = p->err; return rc; }
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MLT_OK;
 }
@@ -1230,7 +1295,7 @@ int mlt_predict_batch_device(mlt_ctx *ctx, int n, int size, const void *d_org, c
   return MLT_OK;
 }
 
-int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp,
+static int predict_batch_single(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp,
                       int32_t *split_mode, float *logits) {
   if (!ctx) return MLT_ERR_ARG;
   if (n < 0 || !split_mode || (n > 0 && (!org || !pred || !poc || !qp))) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
@@ -1337,6 +1402,38 @@ int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const i
   if (nset == 2) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MLT_OK;
+}
+
+int mlt_predict_batch(mlt_ctx *ctx, int n, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp,
+                      int32_t *split_mode, float *logits) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (n < 0 || !split_mode || (n > 0 && (!org || !pred || !poc || !qp))) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (n == 0) return MLT_OK;
+  if (!ctx->peers.empty() && n > 1) {
+    // multi-device context: contiguous shards (device g gets CUs [n g / G, n (g + 1) / G)), one host thread per further device, no
+    // exchange between them; every device runs the single-device path on its shard, so the results are those of one device
+    const int G = 1 + (int)ctx->peers.size(), nlg = st->model.n_logits;
+    const size_t csz = (size_t)size * size;
+    std::vector<mlt_ctx *> devs;
+    for (int g = 0; g < G; ++g) devs.push_back(device_of(ctx, g));
+    std::vector<int> rcs((size_t)G, MLT_OK);
+    auto run = [&](int g) {
+      const int lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G);
+      if (hi > lo) rcs[(size_t)g] = predict_batch_single(devs[(size_t)g], hi - lo, size, org + (size_t)lo * csz, pred + (size_t)lo * csz, poc + lo, qp + lo,
+                                                         split_mode + lo, logits ? logits + (size_t)lo * nlg : nullptr);
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(run, g);
+    run(0);
+    for (std::thread &t : th) t.join();
+    for (int g = 0; g < G; ++g)
+      if (rcs[(size_t)g]) { if (g) ctx->err = "device " + std::to_string(devs[(size_t)g]->device) + ": " + devs[(size_t)g]->err; return rcs[(size_t)g]; }
+    return MLT_OK;
+  }
+  return predict_batch_single(ctx, n, size, org, pred, poc, qp, split_mode, logits);
 }
 
 int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride, int size, int32_t poc, int32_t qp,
@@ -1489,6 +1586,16 @@ int deferred_guard_fixup(mlt_ctx *ctx, SizeState *st, Deferred &df, int b) {
 int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *pred, int pred_stride, int size, int32_t poc, int32_t qp,
                mlt_ticket *ticket) {
   if (!ctx) return MLT_ERR_ARG;
+  if (!ctx->peers.empty() && ticket) {  // multi-device: CUs are dealt round-robin; the ticket's top byte names the device
+    const int G = 1 + (int)ctx->peers.size(), g = (int)(ctx->rr++ % (unsigned)G);
+    if (g > 0) {
+      mlt_ctx *p = device_of(ctx, g);
+      const int rc = mlt_submit(p, org, org_stride, pred, pred_stride, size, poc, qp, ticket);
+      if (rc) { ctx->err = p->err; return rc; }
+      *ticket |= (mlt_ticket)g << 56;
+      return MLT_OK;
+    }
+  }
   if (!org || !pred || !ticket || org_stride < size || pred_stride < size) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
   SizeState *st;
   int rc = check_size(ctx, size, &st);
@@ -1526,6 +1633,10 @@ int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *
 
 int mlt_flush(mlt_ctx *ctx, int size) {
   if (!ctx) return MLT_ERR_ARG;
+  for (mlt_ctx *p : ctx->peers) {
+    const int rc = mlt_flush(p, size);
+    if (rc) { ctx->err = p->err; return rc; }
+  }
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
@@ -1536,6 +1647,16 @@ int mlt_flush(mlt_ctx *ctx, int size) {
 
 int mlt_wait(mlt_ctx *ctx, int size, mlt_ticket ticket, int32_t *split_mode, float *logits_opt) {
   if (!ctx) return MLT_ERR_ARG;
+  if (!ctx->peers.empty()) {
+    const int g = (int)(ticket >> 56);
+    if (g > (int)ctx->peers.size()) { ctx->err = "unknown ticket"; return MLT_ERR_ARG; }
+    if (g > 0) {
+      mlt_ctx *p = device_of(ctx, g);
+      const int rc = mlt_wait(p, size, ticket & (((mlt_ticket)1 << 56) - 1), split_mode, logits_opt);
+      if (rc) ctx->err = p->err;
+      return rc;
+    }
+  }
   if (!split_mode) { ctx->err = "bad argument"; return MLT_ERR_ARG; }
   SizeState *st;
   int rc = check_size(ctx, size, &st);

@@ -11,16 +11,27 @@
 // Header-only; link with -lmltcnn_hip.  One instance per EncCu (the encoder is single-threaded, or one EncCu per
 // thread under WPP / split parallelism, EncCu.cpp:233).
 //
-// Test hooks (environment, read once per instance; none is needed in production):
+// Decisions: the split mode is what the encoder consumes (EncCu.cpp:921 -> EncModeCtrl.cpp:110-149), so this class turns the library's
+// DECISION GUARD on by default (MLT_FLAG_DECISION_GUARD, margin 2 x tolerance): a CU whose decision-head top-2 margin is too small for
+// the fast arithmetic's error bound to guarantee the argmax is re-evaluated with the exact arithmetic before the call returns.
+//
+// Test hooks, compiled in only with -DMLTCNN_TEST_HOOKS (tools/build_vtm.sh does; a production build carries none of them):
 //   MLTCNN_FAULT_INJECT=1      the predictor reports ok() without touching a device and every predictSplitMode() fails (-1):
 //                              exercises the reference's swallow-and-continue contract from the real call site on a box without a GPU
-//   MLTCNN_CALL_DUMP_FILE=path every predictSplitMode() call is appended to `path` (little-endian records, see dumpCall):
+//   MLTCNN_CALL_DUMP_FILE=path every predictSplitMode() call is appended to `path` (little-endian records, see dumpCall; one
+//                              write(2) per record on an O_APPEND descriptor, so instances on several threads cannot interleave):
 //                              tests/test_vtm_encoder.py re-checks each one against the CPU oracle
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <vector>
+#ifdef MLTCNN_TEST_HOOKS
+#include <fcntl.h>
+#include <unistd.h>
+#endif
 
 #include "../include/mltcnn.h"
 
@@ -32,10 +43,14 @@ class SplitPredictor {
  public:
   // weightsDir replaces the hard-coded "/home/ubuntu/whyeo/vtm-mlt-final/torch_model" (EncCu.cpp:899); files are
   // MLTORPQ_splitMode_<S>.mltw (tools/convert_weights.py).  sizeMask: MLT_SIZE_* bits (reference: 128 only, :754).
-  explicit SplitPredictor(const std::string &weightsDir, int device = 0, uint32_t sizeMask = MLT_SIZE_128, uint32_t flags = 0) {
+  // flags: MLT_FLAG_* bits; the default turns the decision guard on (see above).  devices / nDevices: one predictor serving several GPUs
+  // (mlt_config.devices: batches submitted through submitSplitMode() are dealt round-robin); nullptr: `device`.
+  explicit SplitPredictor(const std::string &weightsDir, int device = 0, uint32_t sizeMask = MLT_SIZE_128, uint32_t flags = MLT_FLAG_DECISION_GUARD,
+                          const int *devices = nullptr, int nDevices = 0) {
     mlt_config cfg{};
     cfg.struct_size = sizeof cfg;
     cfg.device = device;
+    for (int i = 0; i < nDevices && i < MLT_MAX_DEVICES && devices; ++i) { cfg.devices[i] = devices[i]; cfg.n_devices = i + 1; }
     cfg.weights_dir = weightsDir.c_str();
     cfg.size_mask = sizeMask;
     for (int &h : cfg.head_index) h = -1;  // reference defaults: element [2] for 128, [0] otherwise (EncCu.cpp:913-919)
@@ -44,9 +59,11 @@ class SplitPredictor {
     cfg.guard_margin = 0.f;  // default threshold when MLT_FLAG_DECISION_GUARD is set
     cfg.tolerance = 0.f;     // default |dlogit| contract (1e-3) for the load-time calibration of the fast arithmetic
     m_mask = sizeMask ? sizeMask : MLT_SIZE_128;
+#ifdef MLTCNN_TEST_HOOKS
     if (const char *d = std::getenv("MLTCNN_CALL_DUMP_FILE")) m_dumpPath = d;
     if (const char *f = std::getenv("MLTCNN_FAULT_INJECT")) m_faultInject = std::atoi(f) != 0;
     if (m_faultInject) return;
+#endif
     const int rc = mlt_init(&cfg, &m_ctx);
     if (rc != MLT_OK) {
       std::fprintf(stderr, "error loading the model\n");  // the reference's message (EncCu.cpp:904)
@@ -101,23 +118,33 @@ class SplitPredictor {
 
  private:
   // one record per call: int32 {magic 0x4D4C5443, cuw, poc, qp, split, nLogits}, float logits[MLT_MAX_LOGITS], int16 org[cuw*cuw], int16 pred[cuw*cuw]
+  // -- built in a buffer and written with ONE write(2) on an O_APPEND descriptor (atomic with respect to other appenders: predictors
+  // of several EncCu threads share one dump file); a failed write is reported once.
   void dumpCall(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, int split, const float *lg) const {
-    std::FILE *f = std::fopen(m_dumpPath.c_str(), "ab");
-    if (!f) return;
+#ifdef MLTCNN_TEST_HOOKS
     const int32_t hdr[6] = {0x4D4C5443, cuw, poc, cuQP, split, mlt_num_logits(cuw)};
-    std::fwrite(hdr, sizeof hdr, 1, f);
-    std::fwrite(lg, sizeof(float), MLT_MAX_LOGITS, f);
+    std::vector<char> rec(sizeof hdr + sizeof(float) * MLT_MAX_LOGITS + 2 * sizeof(Pel) * (size_t)cuw * cuw);
+    char *w = rec.data();
+    std::memcpy(w, hdr, sizeof hdr); w += sizeof hdr;
+    std::memcpy(w, lg, sizeof(float) * MLT_MAX_LOGITS); w += sizeof(float) * MLT_MAX_LOGITS;
     for (int pl = 0; pl < 2; ++pl)
       for (int y = 0; y < cuw; ++y) {
         const Pel *src = (pl ? pred : org) + (ptrdiff_t)y * (pl ? predStride : orgStride);
-        std::fwrite(src, sizeof(Pel), (size_t)cuw, f);
+        std::memcpy(w, src, sizeof(Pel) * (size_t)cuw); w += sizeof(Pel) * (size_t)cuw;
       }
-    std::fclose(f);
+    const int fd = ::open(m_dumpPath.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    const bool ok = fd >= 0 && ::write(fd, rec.data(), rec.size()) == (ssize_t)rec.size();
+    if (fd >= 0) ::close(fd);
+    if (!ok && !m_dumpFailed) { m_dumpFailed = true; std::fprintf(stderr, "mltcnn: cannot append to %s\n", m_dumpPath.c_str()); }
+#else
+    (void)org; (void)orgStride; (void)pred; (void)predStride; (void)cuw; (void)poc; (void)cuQP; (void)split; (void)lg;
+#endif
   }
 
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;
-  bool m_faultInject = false;
+  bool m_faultInject = false;   // (only ever set with MLTCNN_TEST_HOOKS)
+  mutable bool m_dumpFailed = false;
   std::string m_dumpPath;
 };
 

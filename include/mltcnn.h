@@ -83,12 +83,30 @@ typedef struct mlt_config {
   float tolerance;        /* |dlogit| contract the fast arithmetic is calibrated against at load time; <= 0 => 1e-3
                              (BASELINE.json north_star) */
   uint32_t reserved;      /* 0 */
+  /* ---- ABI 3 (struct_size == sizeof(mlt_config); the 56-byte ABI-2 struct is still accepted: one device) ---- */
+  int32_t n_devices;      /* 0: the single `device` above.  k >= 1: devices[0..k-1] -- ONE context serving k GPUs of the node (SURVEY.md 8e
+                             "CTUs within a frame shard across the GPUs"; the encoder is one process): weights are uploaded (and
+                             calibrated) once per device from the one host blob, mlt_predict_batch shards its batch contiguously over the
+                             devices (one host thread each, no exchange between them), mlt_submit deals CUs round-robin and mlt_flush /
+                             mlt_wait / mlt_synchronize / mlt_load_weights / mlt_shutdown address all of them; mlt_predict, the
+                             device-pointer entry, mlt_set_stream and the profile calls address devices[0] (use mlt_device_ctx for the
+                             others).  Results are bit-identical to a one-device context.  An ordinal may be listed more than once
+                             (several contexts on one GPU: how a 1-GPU box exercises this path). */
+  int32_t devices[8];
 } mlt_config;
+#define MLT_MAX_DEVICES 8
+#define MLT_CONFIG_SIZE_ABI2 56
 
 /* Create a context: selects the device, allocates workspaces, loads + folds + packs weights
  * ONCE (the reference re-reads the .pt on every CU, EncCu.cpp:894-900).  Natural home:
  * EncCu::init (EncCu.cpp:233-259).  Thread-compatible: one ctx per EncCu / encoder thread. */
 int mlt_init(const mlt_config *cfg, mlt_ctx **out);
+
+/* Multi-device contexts: number of devices served (1 for a plain context) and the context of devices[index] -- a full single-device
+ * context owned by `ctx` (never shut it down itself), for the calls that address one device (mlt_predict_batch_device with buffers on
+ * that GPU, mlt_set_stream, mlt_profile_*, mlt_arithmetic).  index 0 returns ctx. */
+int mlt_num_devices(const mlt_ctx *ctx);
+mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
 
 /* Load weights for one CU size from an in-memory MLTW blob (format: weights.py).  Used when the
  * blob arrives over RCCL broadcast instead of from weights_dir.  A size configured for the fast arithmetic is

@@ -11,10 +11,14 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
-    # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
-    "s2_wp8": ["CFG_3264_WP=8"],
-    "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"],
+    # round 4: taps per weight step of the exact arithmetic's per-conv kernels (SWEEP_ARGS="--weight-seed 22" = the exact 128 model, "--size 64")
+    "gte_s2_2": ["CFG_GTE_S2=2"],
+    "gte_s2_5": ["CFG_GTE_S2=5"],
+    "gte_s1_3": ["CFG_GTE_S1=3"],
+    "gte_s2_2_s1_3": ["CFG_GTE_S2=2", "CFG_GTE_S1=3"],
 }
+# round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
+#   "s2_wp8": ["CFG_3264_WP=8"], "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"]
 # (the KO_* knock-out knobs of rounds 1-3 were removed from the kernels at the end of round 3; their results are in DESIGN.md)
 
 
@@ -33,7 +37,7 @@ def main():
     else:
         for name in VARIANTS:
             env = dict(os.environ, MLT_TUNING="1", MLT_LIB_PATH=os.path.join(VDIR, f"lib_{name}.so"), MLT_CHUNK="4096")
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")],
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline", "--flags", os.environ.get("SWEEP_FLAGS", "0")] + os.environ.get("SWEEP_ARGS", "").split(),
                                  env=env, capture_output=True, text=True).stdout
             line = [l for l in out.splitlines() if l.startswith("{")]
             if not line:

@@ -25,16 +25,18 @@ def test_exports_match_header(pkg, lib):
 
 
 def test_abi_version_and_logit_counts(lib):
-    assert lib.mlt_abi_version() == 2
+    assert lib.mlt_abi_version() == 3
     assert [lib.mlt_num_logits(s) for s in (128, 64, 32, 16, 8)] == [9, 15, 15, 15, 0]
 
 
 def test_config_struct_layout(pkg):
     # must match `struct mlt_config` in include/mltcnn.h (x86-64 SysV)
-    assert C.sizeof(pkg.capi.MltConfig) == 56
+    assert C.sizeof(pkg.capi.MltConfig) == 96   # ABI 3: the 56-byte ABI-2 struct + n_devices + devices[8] (+ tail padding)
+    assert pkg.capi.MltConfig.n_devices.offset == 56 and pkg.capi.MltConfig.devices.offset == 60
     assert pkg.capi.MltConfig.guard_margin.offset == 44
     assert pkg.capi.MltConfig.tolerance.offset == 48
-    assert C.sizeof(pkg.capi.MltArithInfo) == 32
+    assert C.sizeof(pkg.capi.MltArithInfo) == 40   # ABI 3: + w2_stages, guard_margin
+    assert pkg.capi.MltArithInfo.w2_stages.offset == 32 and pkg.capi.MltArithInfo.guard_margin.offset == 36
     assert pkg.capi.MltConfig.weights_dir.offset == 8
     assert pkg.capi.MltConfig.head_index.offset == 20
     assert C.sizeof(pkg.capi.MltKernelTime) == 72
@@ -46,6 +48,27 @@ def test_init_rejects_bad_config(pkg, lib):
     cfg.struct_size = 4
     assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1  # MLT_ERR_ARG
     assert lib.mlt_init(None, C.byref(h)) == 1
+
+
+def test_device_list_and_abi2_struct_are_validated_before_any_device_is_touched(pkg, lib):
+    """ABI 3: mlt_config carries a device list.  The 56-byte ABI-2 struct is still accepted (it reaches the device check), a device count
+    beyond MLT_MAX_DEVICES is an argument error, and -- without a GPU -- a well-formed list fails with MLT_ERR_NO_DEVICE, not a crash."""
+    import torch
+    h = C.c_void_p()
+    cfg = pkg.capi.MltConfig()
+    cfg.struct_size = C.sizeof(pkg.capi.MltConfig)
+    cfg.n_devices = 9
+    assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1        # MLT_ERR_ARG
+    cfg.n_devices = -1
+    assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1
+    assert lib.mlt_num_devices(None) == 0 and not lib.mlt_device_ctx(None, 0)
+    if not torch.cuda.is_available():
+        cfg.n_devices = 2
+        cfg.devices[0], cfg.devices[1] = 0, 1
+        assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 2    # MLT_ERR_NO_DEVICE
+        cfg.struct_size = 56                                  # an ABI-2 caller: no device list, `device` decides
+        cfg.n_devices = 0
+        assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 2
 
 
 def test_no_gpu_fails_loudly(pkg):

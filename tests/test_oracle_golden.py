@@ -24,9 +24,9 @@ def test_oracle_matches_reference_fixtures(pkg, size):
         dec = 2 if size == 128 else 0  # EncCu.cpp:913-919
         for i in range(case["n"]):
             for h, sl in enumerate(sls):
-                if decisive(exp[i], sl, 1e-3):
+                if decisive(exp[i], sl, 4e-5):   # (twice the fp32 restatement's own distance from the reference; the near-tie family of round 4 lives just above it)
                     assert int(np.argmax(logits[i, sl])) == exp_arg[i][h], (case["name"], i, h)
-            if decisive(exp[i], sls[dec], 1e-3):
+            if decisive(exp[i], sls[dec], 4e-5):
                 assert split[i] == exp_arg[i][dec]
     print(f"size {size}: worst |dlogit| {worst:.2e}")
 

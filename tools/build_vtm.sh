@@ -9,6 +9,8 @@
 #
 #   tools/build_vtm.sh [--ref DIR] [--work DIR] [--jobs N]
 #
+# The binaries are TEST binaries: host/mlt_split_predictor.hpp is compiled with -DMLTCNN_TEST_HOOKS (fault injection + call dump; a production
+# build of the patched encoder carries neither).
 # The anchor (stock VTM-11.0 RDO) needs no second build: MLTCNN_SIZE_MASK=0x100 enables no CU size, so gate() is false
 # for every CU (tests/test_vtm_encoder.py compares its bitstream with the failure-injected and the no-device runs).
 #
@@ -41,7 +43,7 @@ fi
 WNO="-Wno-error=maybe-uninitialized -Wno-error=stringop-overflow -Wno-error=array-bounds -Wno-error=uninitialized -Wno-error=deprecated-declarations -Wno-error=unused-but-set-variable -Wno-error=address -Wno-error=nonnull -Wno-error=restrict -Wno-error=stringop-truncation -Wno-error=format-truncation -Wno-error=misleading-indentation"
 build_one() {  # $1 = build dir name, $2 = extra CXX flags, $3 = output suffix
   mkdir -p "$WORK/$1"
-  (cd "$WORK/$1" && cmake "$WORK/src" -DCMAKE_BUILD_TYPE=Release -DMLTCNN_ROOT="$REPO" -DCMAKE_CXX_FLAGS="$WNO $2" > cmake.log 2>&1) || { tail -20 "$WORK/$1/cmake.log"; exit 4; }
+  (cd "$WORK/$1" && cmake "$WORK/src" -DCMAKE_BUILD_TYPE=Release -DMLTCNN_ROOT="$REPO" -DCMAKE_CXX_FLAGS="$WNO -DMLTCNN_TEST_HOOKS $2" > cmake.log 2>&1) || { tail -20 "$WORK/$1/cmake.log"; exit 4; }
   (cd "$WORK/$1" && make -j"$JOBS" EncoderApp DecoderApp > make.log 2>&1) || { grep -n "error" "$WORK/$1/make.log" | head -20; exit 5; }
   mkdir -p "$REPO/oracle/_ref/vtm"
   # the reference's CMake writes binaries to <src>/bin (BBuildEnv); pick up the freshest EncoderApp / DecoderApp

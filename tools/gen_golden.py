@@ -47,7 +47,7 @@ def reference_model(arch: int):
     return _load(os.path.join(REF_ARCH_DIR, "mlt_cu_or_pq_arch.py"), "ref_cu").GapBigMltCuORPQ()
 
 
-def variant_state_dict(arch, weight_seed, variant, size):
+def variant_state_dict(arch, weight_seed, variant, size, param=0.0):
     sd = synth.make_state_dict(arch, weight_seed)
     if variant == "tie":
         # decision head (EncCu.cpp:913-919): rows 0 and 1 identical and dominant -> exact tie,
@@ -56,6 +56,17 @@ def variant_state_dict(arch, weight_seed, variant, size):
         w, b = sd[f"branch{h}.weight"], sd[f"branch{h}.bias"]
         w[1] = w[0]
         b[1] = b[0]
+        b[2:] -= 1000.0
+    if variant == "near_tie":
+        # decision head: row 1 = row 0 + a small feature-dependent perturbation, the other rows far below -> the top-2 margin of every CU
+        # is a small random number (|margin| ~ 1e-5 ... 2e-3, either sign): the CUs a decision guard exists for (round 4)
+        h = 3 if size == 128 else 1
+        w, b = sd[f"branch{h}.weight"], sd[f"branch{h}.bias"]
+        c = w.shape[1] - 2
+        u = synth.uniform(weight_seed, "near_tie", c).astype(np.float32)
+        w[1] = w[0]
+        w[1, :c] += np.float32(1e-3) * (2.0 * u - 1.0)
+        b[1] = b[0] + np.float32(param)   # param: the shift that centres the margins of the case's CUs on zero (found by gen_golden.py, stored in the fixture)
         b[2:] -= 1000.0
     return sd
 
@@ -102,6 +113,13 @@ CASES = [
     ("dither_w21", 21, "plain", 1034, synth.KIND_DITHER, 3, None),
     ("low_contrast_w21", 21, "plain", 1035, synth.KIND_LOW_CONTRAST, 3, None),
     ("dither_w11", 11, "plain", 1036, synth.KIND_DITHER, 3, None),
+    # round 4: near-ties on the decision head (top-2 margins of 1e-5 ... 2e-3, either sign) on the bench weight set (single pass) and on
+    # two sets of the hi+lo-weights tiers; the new content classes of the two-level flat guard
+    ("near_tie", 10, "near_tie", 1040, synth.KIND_TEXTURE, 16, None),
+    ("near_tie_w13", 13, "near_tie", 1041, synth.KIND_TEXTURE, 12, None),
+    ("near_tie_w23", 23, "near_tie", 1042, synth.KIND_UNIFORM, 8, None),
+    ("partial_near_flat", 10, "plain", 1043, synth.KIND_PARTIAL_NEAR_FLAT, 4, None),
+    ("partial_near_flat_w13", 13, "plain", 1044, synth.KIND_PARTIAL_NEAR_FLAT, 4, None),
 ]
 
 
@@ -121,15 +139,23 @@ def main():
                "reference": "GapBigMltCtuORPQ" if arch == 0 else "GapBigMltCuORPQ",
                "torch": torch.__version__, "cases": []}
         for name, wseed, variant, iseed, kind, n, override in CASES:
-            sd = variant_state_dict(arch, wseed, variant, size)
-            model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-            model.eval()
             org, pred = synth.make_patches(size, n, iseed, kind)
             if override is None:
                 poc, qp = synth.make_scalars(n, iseed)
             else:
                 poc, qp = np.array(override[0], np.int32), np.array(override[1], np.int32)
             x = prep_input(org, pred)
+            param = 0.0
+            if variant == "near_tie":  # centre the top-2 margins of this case's CUs on zero: what is left is +- the feature-dependent part
+                sd0 = variant_state_dict(arch, wseed, variant, size, 0.0)
+                model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd0.items()}, strict=True)
+                model.eval()
+                with torch.no_grad():
+                    hd = model(x, torch.from_numpy(poc.astype(np.int64)), torch.from_numpy(qp.astype(np.int64)))[2 if size == 128 else 0].numpy()
+                param = float(np.float32(-np.median(hd[:, 1] - hd[:, 0])))
+            sd = variant_state_dict(arch, wseed, variant, size, param)
+            model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+            model.eval()
             with torch.no_grad():
                 # one CU per forward, exactly like the encoder (batch 1, EncCu.cpp:869-909)
                 per_cu = [model(x[i:i + 1], torch.tensor([int(poc[i])]), torch.tensor([int(qp[i])])) for i in range(n)]
@@ -139,7 +165,8 @@ def main():
             assert np.abs(logits - logits_b).max() <= 1e-4 * max(1.0, np.abs(logits).max()), "batched vs single"
             argmax = [[int(h[0].argmax().item()) for h in cu] for cu in per_cu]
             out["cases"].append({
-                "name": name, "weight_seed": wseed, "variant": variant, "input_seed": iseed, "kind": kind, "n": n,
+                "name": name, "weight_seed": wseed, "variant": variant, **({"variant_param": param} if variant == "near_tie" else {}),
+                "input_seed": iseed, "kind": kind, "n": n,
                 "poc": [int(v) for v in poc], "qp": [int(v) for v in qp],
                 "blob_sha256": hashlib.sha256(weights.pack_blob(arch, sd)).hexdigest(),
                 "input_sha256": hashlib.sha256(org.tobytes() + pred.tobytes()).hexdigest(),
