@@ -75,7 +75,11 @@ struct GuardSlot {
   int32_t *d_flat = nullptr, *d_idx = nullptr, *d_count = nullptr;
   float *d_lg = nullptr;       // logits for the margin test when the caller wants none
   int32_t *h_count = nullptr;  // pinned
+  bool single = false;         // mlt_predict's slot: one CU, d_flat zero on entry and cleared by the heads kernel (consume-and-clear), the
+                               // selection rides on the heads kernel, and the caller's own result copy brings the count back
 };
+// guard selection fused into the heads kernel of a single-CU launch (HeadArgs.g_*)
+struct GuardTail { int32_t *count, *idx, *flat; int flat_thr, near_thr; float margin; };
 
 // mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
 // hipGraph captured once per CU size, one D2H.
@@ -394,7 +398,7 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
 
 // Whole layer0.0 (composed first layer + conv2 + shortcut + relu) from the raw planes in one kernel (fast, H >= 32).
 int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
-                   long pred_rs, long pred_cs, void *y, int32_t *d_flat) {
+                   long pred_rs, long pred_cs, void *y, int32_t *d_flat, bool flat_is_clear = false) {
   const int h = S / 2;
   const mlt::PackedConv &c2 = m.blocks[0][0].conv2;
   StemBlockArgs a{};
@@ -402,7 +406,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   a.w = m.stem_b.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
   a.flat = d_flat;
   a.w_lo_off = m.stem_b.plane_halves * 2; a.w2_lo_off = c2.plane_halves * 2; a.scale2 = c2.acc_scale;
-  if (d_flat) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
+  if (d_flat && !flat_is_clear) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));  // (flat_is_clear: the consumer of the previous call left it zero)
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
   static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
@@ -493,7 +497,7 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
 // activation planes, so the two models' stages compose freely), the others `m` (single-pass kernels).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
-                mlt::Model *mback = nullptr, unsigned back_mask = 0) {
+                mlt::Model *mback = nullptr, unsigned back_mask = 0, const GuardTail *tail = nullptr, bool flat_is_clear = false) {
   const int S = st.size;
   int rc = ensure_ws(ctx, ws_per_cu(m, S) * (size_t)n);
   if (rc) return rc;
@@ -569,7 +573,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
     if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;
-      if ((rc = run_stem_block(ctx, ms, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat))) return rc;
+      if ((rc = run_stem_block(ctx, ms, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat, flat_is_clear))) return rc;
     } else {
       const bool chain = wants_chain(s, h);
       const bool chain_s2 = wants_s2(s, h);  // the stride-2 conv + shortcut join the launch
@@ -629,6 +633,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
   }
   ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
+  if (tail && n == 1) {
+    ha.g_count = tail->count; ha.g_idx = tail->idx; ha.g_flat = tail->flat; ha.g_flat_thr = tail->flat_thr; ha.g_near_thr = tail->near_thr; ha.g_margin = tail->margin;
+  }
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if ((rc = L.prof_begin("heads", 0.0, 0.0, e0, e1))) return rc;
@@ -687,10 +694,11 @@ struct Planes {  // the two Pel planes of a batch in device memory (element stri
 };
 
 int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs, long pred_cs,
-             const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr) {
-  if (st.w2)  // hi+lo weights in the stages of w2_mask, single pass in the others
-    return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat, &st.model_w2, st.w2_mask);
-  return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat);
+             const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr, const GuardTail *tail = nullptr,
+             bool flat_is_clear = false) {
+  // (hi+lo-weights tiers: the two-plane model in the stages of w2_mask, single pass in the others)
+  return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat,
+                     st.w2 ? &st.model_w2 : nullptr, st.w2 ? st.w2_mask : 0u, tail, flat_is_clear);
 }
 
 // fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
@@ -702,6 +710,13 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc;
   float *lg = d_logits ? d_logits : (st.margin_guard ? g.d_lg : nullptr);
+  if (g.single && n == 1) {
+    // one CU (mlt_predict's captured graph): the selection is a tail of the heads kernel -- no guard_select launch, no memset of the
+    // statistic (the tail clears it for the next call; it is only consumed when the first kernel is the one that produces it: aligned planes,
+    // S >= 64 -- else flat_stat_kernel overwrites it), no separate copy of the count (the caller's result copy carries it)
+    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / 8, (S * S / 4) / 2, st.margin_guard ? ctx->guard_margin : 0.f};
+    return run_main(ctx, st, 1, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg, st.flat_guard ? g.d_flat : nullptr, &tail, true);
+  }
   if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
                      st.flat_guard ? g.d_flat : nullptr))) return rc;
   GuardSelectArgs sa{};
@@ -1451,6 +1466,7 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
     sg.plane = (cs * 2 + 255) / 256 * 256;
     HIP_TRY(ctx, hipHostMalloc((void **)&sg.h_stage, 2 * sg.plane + 256, hipHostMallocDefault));
     HIP_TRY(ctx, hipMalloc((void **)&sg.d_stage, 2 * sg.plane + 256));
+    HIP_TRY(ctx, hipMemset(sg.d_stage + 2 * sg.plane, 0, 256));  // the flat-guard statistic of the single-CU path starts at zero (consume-and-clear)
   }
   // the gather of EncCu.cpp:810-830: rows of `size` Pels out of a `stride`-Pel pitch -> dense planes (pinned)
   for (int y = 0; y < size; ++y) {
@@ -1466,6 +1482,7 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
   const bool guards = st->guards();
   GuardSlot g;
   g.d_count = d_sc + 3; g.d_flat = d_sc + 20; g.d_idx = d_sc + 21; g.d_lg = (float *)(d_sc + 4); g.h_count = h_sc + 3;
+  g.single = true;  // (d_flat was zeroed with the staging buffer and is cleared by every call's heads kernel)
   auto chain = [&]() -> int {  // the kernel chain of one CU (captured into a hipGraph below)
     if (!guards) return run_main(ctx, *st, 1, d_org, size, (long)cs, d_pred, size, (long)cs, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4));
     int r = run_guarded_async(ctx, *st, 1, pl, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4), g);  // its 4-byte count D2H lands in h_sc[3]

@@ -141,6 +141,13 @@ struct HeadArgs {
   const int32_t *poc, *qp;
   float *logits;   // [n][sum classes] or NULL
   int32_t *split;  // [n]
+  // Single-CU launches (n == 1, mlt_predict's captured graph): the guard selection rides on this kernel instead of a launch of its own
+  // (guard_select_kernel: 5 us of a 160 us call).  g_count != NULL: g_count[0] = 1 and g_idx[0] = 0 when CU 0 is flagged by the
+  // flat-content statistic (g_flat, thresholds as GuardSelectArgs) or by the decision-head margin (g_margin > 0), else g_count[0] = 0;
+  // g_flat[0] is CLEARED afterwards (consume-and-clear: the next call's first kernel adds into it, no memset node in the graph).
+  int32_t *g_count, *g_idx, *g_flat;
+  int g_flat_thr, g_near_thr;
+  float g_margin;
 };
 
 // ---- parity guard (fast arithmetic): device-side selection of the CUs that are re-evaluated with the exact arithmetic ----

@@ -306,8 +306,8 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_GTE_S1   // exact arithmetic: taps per weight step, stride-1 (9 taps: 1, 3) / stride-2 + shortcut (10: 1, 2, 5)
 #define CFG_GTE_S1 1
 #endif
-#ifndef CFG_GTE_S2
-#define CFG_GTE_S2 1
+#ifndef CFG_GTE_S2   // round 4 sweep (profiles/r04h_sweep_exact*.txt): 2 taps per step -> 128->256 s2 1.57 -> 1.25 ms, 32->64 s2 1.46 -> 1.33 ms (exact 128 model
+#define CFG_GTE_S2 2 // +2 %), 64x64 model 958 k -> 1.00 M CU/s, 16x16 +3 %; 5 taps do not fit the LDS beside two activation planes
 #endif
 #ifndef CFG_BIG_WP_EXACT  // ... exact arithmetic (small-CU models, maps of 1..16 pixels): 128-pixel tiles, 8 waves
 #define CFG_BIG_WP_EXACT 4
