@@ -345,7 +345,7 @@ def main():
         except subprocess.TimeoutExpired:
             cpu_baseline["torch_port_error"] = "timeout"
     else:
-        sample = min(B, 8 if args.no_cpu_baseline else 64)
+        sample = min(B, args.cpu_sample or (8 if args.no_cpu_baseline else 64))  # (--cpu-sample N: parity over N CUs even without the CPU baseline legs)
         ref, ref_split = oracle.Oracle(blob).forward(org[:sample], pred[:sample], poc[:sample], qp[:sample], threads=min(cores, sample))
     hs, lo = [], 0
     for c in pkg.synth.HEAD_CLASSES[arch]:

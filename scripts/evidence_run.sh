@@ -1,13 +1,15 @@
 #!/bin/bash
 # GPU box: one evidence run -> gpurun_out/<tag>/ (turned into profiles/<tag>_* by scripts/make_profiles.py on the build box).
-#   bash scripts/evidence_run.sh r02a
+#   bash scripts/evidence_run.sh r04k
 # 1. the default bench command (the line the driver records)          -> bench_line.json
 # 2. rocprofv3 --kernel-trace --stats of the same workload            -> stats/out_kernel_stats.csv
 # 3. HBM traffic: separate --pmc FETCH_SIZE / WRITE_SIZE passes       -> fetch/, write/  (MI355X_MICROARCH.md HBM section)
 # 4. MFMA / LDS / wait counters, one --pmc pass per counter group     -> pmc/<group>/
+# 5. round 4: the other arithmetic tiers (weight seeds 11 / 13 / 23 / 24: hi+lo weights in some stages; 22: exact), the encoder's
+#    configuration (decision guard), content mixes (25 % flat-guard content, natural statistics), the small CU sizes, the one-CU timeline
 # Counter passes never combine --pmc with --stats / trace domains other than --kernel-trace.
 set -u
-tag=${1:-r02a}
+tag=${1:-r04k}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -20,5 +22,16 @@ for grp in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ
   name=$(echo $grp | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc/$name -o out -- python3 scripts/prof_run.py 4096 2 > $out/pmc_$name.log 2>&1
 done
+for s in 11 13 23 24; do python3 bench.py --no-cpu-baseline --weight-seed $s > $out/bench_seed$s.json 2>> $out/bench.err; done
+python3 bench.py --no-cpu-baseline --weight-seed 22 --steps 20 --warmup 5 > $out/bench_seed22.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --flags 4 > $out/bench_decision_guard.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --flat-frac 0.25 --steps 20 --warmup 5 > $out/bench_flat25.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --content natural > $out/bench_natural.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --content natural --flags 4 > $out/bench_natural_decision_guard.json 2>> $out/bench.err
+for s in 64 32 16; do python3 bench.py --size $s > $out/bench_s$s.json 2>> $out/bench.err; done
+rocprofv3 --kernel-trace --output-format csv -d $out/lat -o out -- python3 scripts/latency_run.py 60 10 0 > $out/lat.log 2>&1
+python3 scripts/latency_run.py 80 10 4 > $out/latency_modes.txt 2>&1
+python3 scripts/latency_run.py 80 13 4 >> $out/latency_modes.txt 2>&1
+python3 scripts/latency_run.py 80 22 4 >> $out/latency_modes.txt 2>&1
 find $out -name '*.csv' | head -40
 cut -c1-600 $out/bench_line.json

@@ -19,6 +19,28 @@ shutil.copy(os.path.join(run, "stats", "out_kernel_stats.csv"), os.path.join(pro
 shutil.copy(os.path.join(run, "bench_line.json"), os.path.join(prof, f"{tag}_bench_line.json"))
 if os.path.exists(os.path.join(run, "bench_extras.json")):
     shutil.copy(os.path.join(run, "bench_extras.json"), os.path.join(prof, f"{tag}_bench_latency_hoststaged.json"))
+# rocprofv3's own --stats averages EVERY dispatch of a kernel name, the load-time calibration's 96-CU sub-batches included (6 of the 126
+# dispatches of the 128 stage): a second table averages the batch launches only (dispatches longer than half the longest of their name)
+trace = os.path.join(run, "stats", "out_kernel_trace.csv")
+if os.path.exists(trace):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(prof, f"{tag}_bench_kernel_batch_launches.csv"), "w") as o:
+        o.write("# from the same rocprofv3 --kernel-trace --stats run as %s_bench_kernel_stats.csv: per kernel, the dispatches longer than half the longest one (= the 4096-CU batch launches)\n" % tag)
+        o.write("kernel,batch_dispatches,all_dispatches,avg_ns_batch_dispatches,avg_ns_all_dispatches\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            big = [x for x in v if x > 0.5 * max(v)]
+            o.write('"%s",%d,%d,%.1f,%.1f\n' % (k[:110], len(big), len(v), sum(big) / len(big), sum(v) / len(v)))
+for f in sorted(glob.glob(os.path.join(run, "bench_*.json"))):  # round 4: the other tiers / content mixes / sizes of the same run
+    base = os.path.basename(f)
+    if base not in ("bench_line.json", "bench_extras.json"):
+        shutil.copy(f, os.path.join(prof, f"{tag}_{base}"))
+if os.path.exists(os.path.join(run, "lat", "out_kernel_trace.csv")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "latency_timeline.py"), os.path.join(run, "lat", "out_kernel_trace.csv"),
+                           os.path.join(prof, f"{tag}_single_cu_timeline.csv")])
+if os.path.exists(os.path.join(run, "latency_modes.txt")):
+    open(os.path.join(prof, f"{tag}_latency_modes.txt"), "w").write("".join(l for l in open(os.path.join(run, "latency_modes.txt")) if "amdgpu.ids" not in l))
 sig = json.load(open(os.path.join(run, "bench_line.json")))["derived"]["source_sig"]  # sources the evidence run was built from
 subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_traffic_json.py"),
                        os.path.join(run, "fetch", "out_counter_collection.csv"), os.path.join(run, "write", "out_counter_collection.csv"),
