@@ -92,6 +92,29 @@ def test_failed_inference_means_full_rdo_from_the_real_call_site(tmp_path):
     _decode_matches_recon(tmp, "inject")
 
 
+def test_probe_and_replay_over_wpp_diagonals_writes_the_serial_bitstream(tmp_path):
+    """SURVEY 8(f) N3, encoder half (round 4, opt-in patch + MLTCNN_BATCH=1): EncSlice::encodeCtus probes every CTU of a WPP anti-diagonal
+    (compressCtu up to the CNN call site: the CU is submitted, the CTU abandoned), flushes the batch and then codes the CTUs in diagonal
+    order, restoring per row what the raster loop carries implicitly (CABAC contexts, HMVP table, previous QP, palette predictor).  Here,
+    without a GPU, every submit fails (fault injection) and every CTU ends in full RDO -- the scheduling itself is what is under test: the
+    bitstream must be the serial encoder's, bit for bit (WaveFrontSynchro on in both), and decode to the reconstruction."""
+    tmp = str(tmp_path)
+    yuv = _yuv(tmp)
+    log = os.path.join(tmp, "batch.log")
+    runs = {"serial": _env(MLTCNN_FAULT_INJECT="1"), "batch": _env(MLTCNN_FAULT_INJECT="1", MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)}
+    procs = {k: subprocess.Popen(_encode_cmd(yuv, k, tmp) + ["--WaveFrontSynchro=1"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k, e in runs.items()}
+    logs = {k: p.communicate(timeout=900)[0] for k, p in procs.items()}
+    for k, p in procs.items():
+        assert p.returncode == 0, logs[k][-3000:]
+    assert logs["serial"].count("Hello") == logs["batch"].count("Hello") >= 2 * 6   # every gated CU reached setNewModeList(-1) exactly once in both
+    sha = {k: hashlib.sha256(open(os.path.join(tmp, k + ".bin"), "rb").read()).hexdigest() for k in runs}
+    assert sha["serial"] == sha["batch"], sha
+    diag = [l.split() for l in open(log)]
+    assert len(diag) == 2 * 5 and max(int(l[7]) for l in diag) == 2          # 3 x 2 CTUs: diagonals of 1, 1, 2, 1, 1 CTUs in each inter picture
+    _decode_matches_recon(tmp, "batch")
+
+
 def read_call_dump(path):
     """Records written by mlt::SplitPredictor::dumpCall (host/mlt_split_predictor.hpp)."""
     out = []
@@ -145,3 +168,38 @@ def test_encode_on_the_gpu_every_call_matches_the_oracle(pkg, tmp_path):
     assert err <= 1e-3, err
     assert flat >= 2   # the constant CTU really reached the predictor (flat-content guard path inside mlt_predict)
     _decode_matches_recon(tmp, "gpu")
+
+
+@pytest.mark.gpu
+def test_probe_and_replay_batches_real_decisions_on_the_gpu(pkg, tmp_path):
+    """The same on the MI355X with real decisions, on a 1024 x 512 clip (8 x 4 CTUs: anti-diagonals of up to 4 CTUs): the encode that
+    submits every diagonal's CUs as ONE batch (mlt_submit / mlt_flush / mlt_wait behind SplitPredictor) writes the bitstream of the serial
+    encode that calls mlt_predict CU by CU, batches of >= 3 CUs really occur, and the stream decodes to the reconstruction."""
+    import torch
+    assert torch.cuda.is_available()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synth_yuv
+    tmp = str(tmp_path)
+    w, h = 1024, 512
+    yuv = os.path.join(tmp, "wide.yuv")
+    make_synth_yuv.write_yuv(yuv, make_synth_yuv.make_frames(w, h, FRAMES, 11))
+    blob = pkg.weights.synthetic_blob(pkg.synth.ARCH_CTU, 10)
+    wdir = os.path.join(tmp, "torch_model")
+    os.makedirs(wdir)
+    open(os.path.join(wdir, "MLTORPQ_splitMode_128.mltw"), "wb").write(blob)
+    log = os.path.join(tmp, "batch.log")
+
+    def cmd(tag):
+        return [ENC, "-c", CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(FRAMES), "--InputBitDepth=10", "--InputChromaFormat=420",
+                "-q", "32", "--WaveFrontSynchro=1", "-b", os.path.join(tmp, tag + ".bin"), "-o", os.path.join(tmp, tag + "_rec.yuv")]
+    out = {}
+    for tag, env in (("serial", _env(MLTCNN_WEIGHTS_DIR=wdir)), ("batch", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log))):
+        r = subprocess.run(cmd(tag), env=env, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert "error" not in r.stderr and r.stdout.count("Hello") == 0, r.stderr[-2000:]
+        out[tag] = hashlib.sha256(open(os.path.join(tmp, tag + ".bin"), "rb").read()).hexdigest()
+    assert out["serial"] == out["batch"], out
+    sizes = [int(l.split()[7]) for l in open(log)]
+    print(f"probe and replay on the GPU: {len(sizes)} batches over {FRAMES - 1} inter pictures, sizes {sorted(set(sizes))}, {sum(sizes)} CUs; bitstream == serial")
+    assert max(sizes) >= 3 and sum(sizes) == (FRAMES - 1) * 32
+    _decode_matches_recon(tmp, "batch")

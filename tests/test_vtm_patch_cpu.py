@@ -12,6 +12,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/vtm-mlt-cpp"
 PATCH = os.path.join(ROOT, "patches", "vtm-mlt-cpp-mltcnn.patch")
+PATCH_N3 = os.path.join(ROOT, "patches", "vtm-mlt-cpp-mltcnn-n3.patch")   # opt-in encoder-side batching, applies on top of PATCH
+N3_EXTRA = ["source/Lib/EncoderLib/EncModeCtrl.h"]
 FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "CMakeLists.txt", "source/Lib/EncoderLib/CMakeLists.txt",
          "source/Lib/EncoderLib/EncSlice.cpp"]
 
@@ -58,3 +60,36 @@ def test_patched_enccu_compiles_against_the_reference_headers(patched):
     cmd = ["g++", "-std=c++14", "-fsyntax-only", "-w"] + [x for i in inc for x in ("-I", i)] + [str(patched / FILES[0])]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_n3_patch_applies_on_top_with_zero_fuzz_and_compiles(patched, tmp_path):
+    """SURVEY 8(f) N3, encoder half (round 4): patches/vtm-mlt-cpp-mltcnn-n3.patch -- probe and replay over WPP anti-diagonals inside
+    EncSlice::encodeCtus -- is what the generator writes, applies to the N1-patched tree with zero fuzz, keeps the setNewModeList call where
+    it was, and the files it touches pass g++ -fsyntax-only against the reference's headers."""
+    out = tmp_path / "regen_n3.patch"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_vtm_patch.py"), "--n3", "--out", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == open(PATCH_N3, "rb").read(), "patches/vtm-mlt-cpp-mltcnn-n3.patch is stale: run tools/make_vtm_patch.py --n3"
+    d = tmp_path / "tree"
+    shutil.copytree(patched, d)
+    for f in N3_EXTRA:
+        os.makedirs(os.path.dirname(d / f), exist_ok=True)
+        shutil.copy(os.path.join(REF, f), d / f)
+    # (a header reached through another header of the same directory is looked up next to THAT header first: the untouched EncoderLib
+    # headers must sit beside the patched ones for the syntax check)
+    for h in os.listdir(os.path.join(REF, "source/Lib/EncoderLib")):
+        if h.endswith(".h") and not (d / "source/Lib/EncoderLib" / h).exists():
+            shutil.copy(os.path.join(REF, "source/Lib/EncoderLib", h), d / "source/Lib/EncoderLib" / h)
+    r = subprocess.run(["patch", "-p1", "--fuzz=0", "--no-backup-if-mismatch", "-i", PATCH_N3], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0 and "fuzz" not in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
+    src = (d / FILES[0]).read_text()
+    assert src.count("m_modeCtrl->setNewModeList(*tempCS, partitioner, predictedSplitMode, currTestMode.qp);") == 1
+    assert "m_cnnSplitPredictor->submitSplitMode(" in src and "m_cnnSplitPredictor->waitSplitMode(" in src and "m_modeCtrl->abortCTU();" in src
+    sl = (d / FILES[4]).read_text()
+    assert "MLTCNN_BATCH" in sl and "rowCtx[ctuYPosInCtus] = pCABACWriter->getCtx();" in sl
+    inc = [str(d / "source/Lib/EncoderLib"), str(d / "source/Lib"), REF + "/source/Lib/EncoderLib", REF + "/source/Lib",
+           REF + "/source/Lib/CommonLib", os.path.join(ROOT, "host"), os.path.join(ROOT, "include")]
+    for f in (FILES[0], FILES[4]):
+        cmd = ["g++", "-std=c++14", "-fsyntax-only", "-w"] + [x for i in inc for x in ("-I", i)] + [str(d / f)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (f, r.stderr[-3000:])

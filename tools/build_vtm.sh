@@ -33,11 +33,15 @@ done
 [ -f "$REPO/fastintercu-vvc_amd/libmltcnn_hip.so" ] || (cd "$REPO" && python -c "import __graft_entry__ as g; g.build()")
 
 mkdir -p "$WORK"
-if [ ! -f "$WORK/src/.patched" ]; then
+# N1 (the call-site replacement) and, on top of it, the opt-in N3 patch (encoder-side batching: probe and replay over WPP anti-diagonals;
+# dormant unless MLTCNN_BATCH=1 -- without it the binary runs the N1 code path).  The scratch tree is re-made when either patch changed.
+PATCHSUM=$(cat "$REPO/patches/vtm-mlt-cpp-mltcnn.patch" "$REPO/patches/vtm-mlt-cpp-mltcnn-n3.patch" | sha256sum | cut -c1-16)
+if [ ! -f "$WORK/src/.patched" ] || [ "$(cat "$WORK/src/.patched")" != "$PATCHSUM" ]; then
   rm -rf "$WORK/src"; mkdir -p "$WORK/src"
   (cd "$REF" && cp -r CMakeLists.txt cmake source cfg "$WORK/src/")
   (cd "$WORK/src" && patch -p1 --fuzz=0 < "$REPO/patches/vtm-mlt-cpp-mltcnn.patch")
-  touch "$WORK/src/.patched"
+  (cd "$WORK/src" && patch -p1 --fuzz=0 < "$REPO/patches/vtm-mlt-cpp-mltcnn-n3.patch")
+  echo "$PATCHSUM" > "$WORK/src/.patched"
 fi
 
 WNO="-Wno-error=maybe-uninitialized -Wno-error=stringop-overflow -Wno-error=array-bounds -Wno-error=uninitialized -Wno-error=deprecated-declarations -Wno-error=unused-but-set-variable -Wno-error=address -Wno-error=nonnull -Wno-error=restrict -Wno-error=stringop-truncation -Wno-error=format-truncation -Wno-error=misleading-indentation"

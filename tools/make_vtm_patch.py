@@ -117,32 +117,217 @@ def patch_encslice_cpp(t):
     return cut(t, "#include <opencv2/opencv.hpp>", "#include <opencv2/highgui.hpp>", "", "EncSlice.cpp OpenCV includes")
 
 
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) N3, encoder half (round 4): an OPT-IN second patch on top of the N1 patch (--n3 -> patches/vtm-mlt-cpp-mltcnn-n3.patch).
+# "Probe and replay" inside EncSlice::encodeCtus, for pictures coded with WaveFrontSynchro (entropy_coding_sync) and MLTCNN_BATCH=1:
+#   for every WPP anti-diagonal (CTUs with equal x + 2y: mutually independent, INTEGRATION.md 7 rule 1)
+#     1. PROBE each of its CTUs: compressCtu runs up to the CNN call site of the 128x128 CU (affine merge + merge / skip checks), where the
+#        CU is SUBMITTED to the predictor (mlt_submit) instead of evaluated, and the CTU is abandoned -- nothing of it has reached the
+#        picture-level coding structure, the mode-control stack is cleared, the CABAC estimator gets its start-of-CTU contexts back;
+#     2. flush: the submitted CUs run as ONE batch on the GPU(s);
+#     3. code the CTUs for real, in raster order within the diagonal: the call site now only collects its ticket (mlt_wait).
+# The encoder keeps ONE running set of per-row states in raster order (CABAC contexts, HMVP table, previous QP, palette predictor); in
+# diagonal order they are saved after every coded CTU and restored before the next CTU of that row.  The bitstream is the serial
+# encoder's, bit for bit (tests/test_vtm_encoder.py) -- the decisions are the same, only when the GPU computes them changes.
+N3_FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "source/Lib/EncoderLib/EncModeCtrl.h",
+            "source/Lib/EncoderLib/EncSlice.cpp"]
+
+
+def n3_enccu_cpp(t):
+    t = replace_once(t,
+                     "    xCompressCU(tempCS, bestCS, partitioner);\n    cs.slice->m_mapPltCost[0].clear();\n",
+                     "    xCompressCU(tempCS, bestCS, partitioner);\n"
+                     "    if( m_cnnProbe )\n"
+                     "    {\n"
+                     "        // probe pass (SURVEY 8f N3): the CTU was abandoned at the CNN call site (or before any other mode ran): nothing has been\n"
+                     "        // written to the picture-level structure; the estimator gets its start-of-CTU contexts back\n"
+                     "        m_CABACEstimator->getCtx() = m_CurrCtx->start;\n"
+                     "        m_CurrCtx                  = 0;\n"
+                     "        return;\n"
+                     "    }\n"
+                     "    cs.slice->m_mapPltCost[0].clear();\n", "compressCtu probe exit")
+    t = replace_once(t,
+                     "        EncTestMode currTestMode = m_modeCtrl->currTestMode();\n        currTestMode.maxCostAllowed = maxCostAllowed;\n",
+                     "        EncTestMode currTestMode = m_modeCtrl->currTestMode();\n        currTestMode.maxCostAllowed = maxCostAllowed;\n"
+                     "        if( m_cnnProbe && currTestMode.type != ETM_AFFINE && currTestMode.type != ETM_MERGE_SKIP )\n"
+                     "        {\n"
+                     "            m_modeCtrl->abortCTU();   // probe pass: only the two checks in front of the CNN call run; this CTU never reaches it\n"
+                     "            return;\n"
+                     "        }\n", "probe guard")
+    t = replace_once(t,
+                     "                predictedSplitMode = m_cnnSplitPredictor->predictSplitMode(orgY.buf, orgY.stride, predY.buf, predY.stride, cuw, poc, cuQP);\n",
+                     "                const PreCalcValues &cnnPcv = *tempCS->pcv;\n"
+                     "                const size_t ctuAddr = (size_t) ( cuy / cnnPcv.maxCUHeight ) * cnnPcv.widthInCtus + cux / cnnPcv.maxCUWidth;\n"
+                     "                if( m_cnnProbe )\n"
+                     "                {\n"
+                     "                    // probe pass: stage this CU for the batch of its anti-diagonal and abandon the CTU\n"
+                     "                    mlt_ticket tk = 0;\n"
+                     "                    if( ctuAddr < m_cnnTicket.size() && m_cnnSplitPredictor->submitSplitMode(orgY.buf, orgY.stride, predY.buf, predY.stride, cuw, poc, cuQP, &tk) )\n"
+                     "                        m_cnnTicket[ctuAddr] = (long long) tk + 1;\n"
+                     "                    m_modeCtrl->abortCTU();\n"
+                     "                    return;\n"
+                     "                }\n"
+                     "                if( ctuAddr < m_cnnTicket.size() && m_cnnTicket[ctuAddr] )\n"
+                     "                {\n"
+                     "                    // replay: the decision was computed with the rest of the diagonal's batch\n"
+                     "                    predictedSplitMode = m_cnnSplitPredictor->waitSplitMode(cuw, (mlt_ticket) ( m_cnnTicket[ctuAddr] - 1 ));\n"
+                     "                    m_cnnTicket[ctuAddr] = 0;\n"
+                     "                }\n"
+                     "                else\n"
+                     "                predictedSplitMode = m_cnnSplitPredictor->predictSplitMode(orgY.buf, orgY.stride, predY.buf, predY.stride, cuw, poc, cuQP);\n",
+                     "call site")
+    t = replace_once(t, "void EncCu::compressCtu( CodingStructure& cs,",
+                     "bool EncCu::cnnBatchingAvailable() const { return m_cnnSplitPredictor && m_cnnSplitPredictor->ok(); }\n"
+                     "void EncCu::cnnFlush( int cuw ) { if( m_cnnSplitPredictor ) m_cnnSplitPredictor->flush( cuw ); }\n\n"
+                     "void EncCu::compressCtu( CodingStructure& cs,", "helpers")
+    return t
+
+
+def n3_enccu_h(t):
+    t = replace_once(t, "  mlt::SplitPredictor  *m_cnnSplitPredictor = nullptr;   // one per EncCu (thread)\n",
+                     "  mlt::SplitPredictor  *m_cnnSplitPredictor = nullptr;   // one per EncCu (thread)\n"
+                     "  // SURVEY 8f N3 (probe and replay, EncSlice::encodeCtus): probe mode abandons a CTU at the CNN call site after submitting its CU;\n"
+                     "  // m_cnnTicket[ctu raster address] = ticket + 1 of a submitted CU (0: none)\n"
+                     "  bool                  m_cnnProbe = false;\n"
+                     "  std::vector<long long> m_cnnTicket;\n", "members")
+    t = replace_once(t, "  void  compressCtu         ( CodingStructure& cs,",
+                     "  void  setCnnProbe         ( bool on )                 { m_cnnProbe = on; }\n"
+                     "  void  cnnResetTickets     ( size_t numCtus )          { m_cnnTicket.assign( numCtus, 0 ); }\n"
+                     "  bool  cnnBatchingAvailable() const;\n"
+                     "  void  cnnFlush            ( int cuw = 128 );\n"
+                     "  void  compressCtu         ( CodingStructure& cs,", "methods")
+    return t
+
+
+def n3_encmodectrl_h(t):
+    return replace_once(t, "    virtual void finishCULevel        ( Partitioner &partitioner )                                                            = 0;\n",
+                        "    virtual void finishCULevel        ( Partitioner &partitioner )                                                            = 0;\n"
+                        "    // SURVEY 8f N3 probe pass: drop the abandoned CTU's mode stack WITHOUT finishCULevel's book-keeping (which would cache the\n"
+                        "    // abandoned CU's best mode for reuse and change the replay)\n"
+                        "    void abortCTU() { m_ComprCUCtxList.clear(); }\n", "abortCTU")
+
+
+def n3_encslice_cpp(t):
+    t = replace_once(t,
+                     "  // for every CTU in the slice\n  for( uint32_t ctuIdx = 0; ctuIdx < pcSlice->getNumCtuInSlice(); ctuIdx++ )\n  {\n"
+                     "    const int32_t ctuRsAddr = pcSlice->getCtuAddrInSlice( ctuIdx );\n",
+                     "  // SURVEY 8f N3, encoder half (opt-in: MLTCNN_BATCH=1): probe-and-replay over WPP anti-diagonals.  Needs entropy-coding sync (every CTU row\n"
+                     "  // starts from the state after the first CTU of the row above, so the CTUs with equal x + 2y are mutually independent), one tile, one\n"
+                     "  // slice per picture, no per-CTU lambda adaptation; anything else keeps the raster loop.  sched: (ctuIdx, phase) with phase 0 = code,\n"
+                     "  // 1 = probe (submit the 128x128 CU's planes to the CNN, abandon the CTU), 2 = flush the submitted CUs as one batch.\n"
+                     "  const uint32_t heightInCtus = pcv.heightInCtus;\n"
+                     "  static const bool cnnBatchEnv = std::getenv( \"MLTCNN_BATCH\" ) && std::atoi( std::getenv( \"MLTCNN_BATCH\" ) ) != 0;\n"
+                     "  const bool cnnBatch = cnnBatchEnv && pEncLib->getEntropyCodingSyncEnabledFlag() && !pcSlice->isIntra() && cs.pps->getNumTiles() == 1\n"
+                     "                        && pcSlice->getNumCtuInSlice() == widthInCtus * heightInCtus && pcSlice->getCtuAddrInSlice( 0 ) == 0\n"
+                     "                        && !pCfg->getUseRateCtrl() && !pCfg->getUsePerceptQPA() && m_pcCuEncoder->cnnBatchingAvailable();\n"
+                     "  std::vector<std::pair<uint32_t, int>> sched;\n"
+                     "  if( cnnBatch )\n"
+                     "  {\n"
+                     "    m_pcCuEncoder->cnnResetTickets( widthInCtus * heightInCtus );\n"
+                     "    for( uint32_t d = 0; d < widthInCtus + 2 * heightInCtus; d++ )\n"
+                     "    {\n"
+                     "      std::vector<uint32_t> diag;\n"
+                     "      for( uint32_t y = 0; y < heightInCtus && 2 * y <= d; y++ )\n"
+                     "        if( d - 2 * y < widthInCtus ) diag.push_back( y * widthInCtus + ( d - 2 * y ) );\n"
+                     "      int probed = 0;\n"
+                     "      for( uint32_t a : diag )   // only CTUs whose 128x128 CU lies inside the picture reach the CNN (the gate, EncCu.cpp:746-756)\n"
+                     "        if( ( a % widthInCtus + 1 ) * pcv.maxCUWidth <= pcv.lumaWidth && ( a / widthInCtus + 1 ) * pcv.maxCUHeight <= pcv.lumaHeight ) { sched.push_back( { a, 1 } ); probed++; }\n"
+                     "      if( probed ) sched.push_back( { 0, 2 } );\n"
+                     "      for( uint32_t a : diag ) sched.push_back( { a, 0 } );\n"
+                     "      if( probed )\n"
+                     "        if( const char *lg = std::getenv( \"MLTCNN_BATCH_LOG\" ) )\n"
+                     "          if( FILE *f = std::fopen( lg, \"a\" ) ) { std::fprintf( f, \"poc %d diagonal %u ctus %d probed %d\\n\", pcSlice->getPOC(), d, (int) diag.size(), probed ); std::fclose( f ); }\n"
+                     "    }\n"
+                     "  }\n"
+                     "  else\n"
+                     "    for( uint32_t i = 0; i < pcSlice->getNumCtuInSlice(); i++ ) sched.push_back( { i, 0 } );\n"
+                     "  // per-row encoder state that the raster loop carries implicitly from a CTU to its right-hand neighbour\n"
+                     "  std::vector<Ctx>           rowCtx( cnnBatch ? heightInCtus : 0 );\n"
+                     "  std::vector<LutMotionCand> rowLut( cnnBatch ? heightInCtus : 0 );\n"
+                     "  std::vector<PLTBuf>        rowPLT( cnnBatch ? heightInCtus : 0 );\n"
+                     "  std::vector<int>           rowPrevQP( cnnBatch ? 2 * heightInCtus : 0 );\n"
+                     "\n"
+                     "  // for every CTU in the slice\n  for( size_t schedIdx = 0; schedIdx < sched.size(); schedIdx++ )\n  {\n"
+                     "    const uint32_t ctuIdx   = sched[schedIdx].first;\n"
+                     "    const int      cnnPhase = sched[schedIdx].second;\n"
+                     "    if( cnnPhase == 2 ) { m_pcCuEncoder->cnnFlush(); continue; }\n"
+                     "    const int32_t ctuRsAddr = pcSlice->getCtuAddrInSlice( ctuIdx );\n", "loop head")
+    t = replace_once(t,
+                     "    DTRACE_UPDATE( g_trace_ctx, std::make_pair( \"ctu\", ctuRsAddr ) );\n\n    if( pCfg->getSwitchPOC() != pcPic->poc || -1 == pCfg->getDebugCTU() )\n",
+                     "    DTRACE_UPDATE( g_trace_ctx, std::make_pair( \"ctu\", ctuRsAddr ) );\n\n"
+                     "    if( cnnBatch && ctuXPosInCtus > 0 )\n"
+                     "    {\n"
+                     "      // diagonal order: what CTU (x - 1, y) left behind (the first CTU of a row is initialised below exactly as in raster order)\n"
+                     "      pCABACWriter->getCtx() = rowCtx[ctuYPosInCtus];\n"
+                     "      cs.motionLut           = rowLut[ctuYPosInCtus];\n"
+                     "      cs.setPrevPLT( rowPLT[ctuYPosInCtus] );\n"
+                     "      prevQP[0] = rowPrevQP[2 * ctuYPosInCtus]; prevQP[1] = rowPrevQP[2 * ctuYPosInCtus + 1];\n"
+                     "    }\n\n"
+                     "    if( pCfg->getSwitchPOC() != pcPic->poc || -1 == pCfg->getDebugCTU() )\n", "row state restore")
+    t = replace_once(t,
+                     "  if (pCfg->getSwitchPOC() != pcPic->poc || ctuRsAddr >= pCfg->getDebugCTU())\n    m_pcCuEncoder->compressCtu( cs, ctuArea, ctuRsAddr, prevQP, currQP );\n",
+                     "    if( cnnPhase == 1 )\n"
+                     "    {\n"
+                     "      m_pcCuEncoder->setCnnProbe( true );\n"
+                     "      m_pcCuEncoder->compressCtu( cs, ctuArea, ctuRsAddr, prevQP, currQP );   // runs up to the CNN call site, submits, abandons the CTU\n"
+                     "      m_pcCuEncoder->setCnnProbe( false );\n"
+                     "      continue;\n"
+                     "    }\n"
+                     "  if (pCfg->getSwitchPOC() != pcPic->poc || ctuRsAddr >= pCfg->getDebugCTU())\n    m_pcCuEncoder->compressCtu( cs, ctuArea, ctuRsAddr, prevQP, currQP );\n",
+                     "probe call")
+    t = replace_once(t,
+                     "    m_uiPicTotalBits += actualBits;\n    m_uiPicDist       = cs.dist;\n    // for last Ctu in the slice\n",
+                     "    m_uiPicTotalBits += actualBits;\n    m_uiPicDist       = cs.dist;\n"
+                     "    if( cnnBatch )\n"
+                     "    {\n"
+                     "      rowCtx[ctuYPosInCtus] = pCABACWriter->getCtx();\n"
+                     "      rowLut[ctuYPosInCtus] = cs.motionLut;\n"
+                     "      cs.storePrevPLT( rowPLT[ctuYPosInCtus] );\n"
+                     "      rowPrevQP[2 * ctuYPosInCtus] = prevQP[0]; rowPrevQP[2 * ctuYPosInCtus + 1] = prevQP[1];\n"
+                     "    }\n"
+                     "    // for last Ctu in the slice\n", "row state save")
+    return t
+
+
+N3_PATCHERS = {N3_FILES[0]: n3_enccu_cpp, N3_FILES[1]: n3_enccu_h, N3_FILES[2]: n3_encmodectrl_h, N3_FILES[3]: n3_encslice_cpp}
+
 PATCHERS = {FILES[0]: patch_enccu_cpp, FILES[1]: patch_enccu_h, FILES[2]: patch_top_cmake, FILES[3]: patch_lib_cmake, FILES[4]: patch_encslice_cpp}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference/vtm-mlt-cpp")
-    ap.add_argument("--out", default=os.path.join(ROOT, "patches", "vtm-mlt-cpp-mltcnn.patch"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--n3", action="store_true", help="write the opt-in encoder-side batching patch (applies ON TOP of the N1 patch)")
     args = ap.parse_args()
+    if args.out is None:
+        args.out = os.path.join(ROOT, "patches", "vtm-mlt-cpp-mltcnn-n3.patch" if args.n3 else "vtm-mlt-cpp-mltcnn.patch")
+    files = N3_FILES if args.n3 else FILES
     tmp = tempfile.mkdtemp(prefix="vtmpatch_")
     try:
-        for f in FILES:
+        for f in files:
             for side in ("a", "b"):
                 os.makedirs(os.path.dirname(os.path.join(tmp, side, f)), exist_ok=True)
-            shutil.copy(os.path.join(args.ref, f), os.path.join(tmp, "a", f))
             with open(os.path.join(args.ref, f), newline="") as fh:
                 text = fh.read()
             crlf = "\r\n" in text
             if crlf:
                 text = text.replace("\r\n", "\n")
-            text = PATCHERS[f](text)
+            if args.n3:  # side a = the N1-patched file (or the reference's own where N1 does not touch it), side b = N1 + N3
+                base = PATCHERS[f](text) if f in PATCHERS else text
+                text = N3_PATCHERS[f](base)
+                with open(os.path.join(tmp, "a", f), "w", newline="") as fh:
+                    fh.write(base.replace("\n", "\r\n") if crlf else base)
+            else:
+                shutil.copy(os.path.join(args.ref, f), os.path.join(tmp, "a", f))
+                text = PATCHERS[f](text)
             if crlf:
                 text = text.replace("\n", "\r\n")
             with open(os.path.join(tmp, "b", f), "w", newline="") as fh:
                 fh.write(text)
         chunks = []
-        for f in FILES:
+        for f in files:
             r = subprocess.run(["diff", "-u", "--label", "a/" + f, "--label", "b/" + f, os.path.join("a", f), os.path.join("b", f)],
                                cwd=tmp, capture_output=True)
             if r.returncode not in (0, 1):
