@@ -3,9 +3,10 @@
 Same role and same import rules as oracle.py / mlt_oracle.c: only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may use it.  It is an independent cross-check of the C oracle (different operators, different summation
 order, NCHW) and the restatement closest to what the reference's CPU path would execute (LibTorch CPU backend,
-EncCu.cpp:869-921).  As a BASELINE it is not used: on the GPU box's 256 host threads PyTorch's CPU convolutions ran
-3.6 CU/s on this network (thread oversubscription on 64-CU batches) against 203 CU/s for the OpenMP-over-CUs C oracle,
-so bench.py keeps timing the C oracle.  Restates, with torch.nn.functional only (no reference module is imported):
+EncCu.cpp:869-921).  It IS bench.py's cpu_baseline (oracle/cpu_baseline.py times it in child processes: one CU at a time with a
+thread sweep, batch 64, and the batch sharded over one single-threaded process per physical core -- the best row, 977 CU/s on the
+GPU box's 128 cores in round 4, is `cpu_baseline.value`; the OpenMP-over-CUs C oracle, 220 CU/s, is one more row of the same table).
+Restates, with torch.nn.functional only (no reference module is imported):
   preprocessing  EncCu.cpp:816,827 (uint16 cast), :833 (absdiff), :836,838 (* (float)(1/1023)), :848-867 (clip)
   network        mlt_ctu_or_pq_arch.py:32-57 (BasicBlock), :273-299 (forward: stem without bn/relu, GAP, heads with
                  [features, poc, qp]), mlt_cu_or_pq_arch.py:96-128 (five stages, four heads)

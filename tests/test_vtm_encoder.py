@@ -41,7 +41,7 @@ def _a_failed_encoder_build_is_a_failure_not_a_skip():
 def _env(**extra):
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "fastintercu-vvc_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
-    for k in ("MLTCNN_FAULT_INJECT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS"):
+    for k in ("MLTCNN_FAULT_INJECT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS", "MLTCNN_DEVICES", "MLTCNN_BATCH", "MLTCNN_BATCH_LOG"):
         env.pop(k, None)
     env.update(extra)
     return env
@@ -193,12 +193,15 @@ def test_probe_and_replay_batches_real_decisions_on_the_gpu(pkg, tmp_path):
         return [ENC, "-c", CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(FRAMES), "--InputBitDepth=10", "--InputChromaFormat=420",
                 "-q", "32", "--WaveFrontSynchro=1", "-b", os.path.join(tmp, tag + ".bin"), "-o", os.path.join(tmp, tag + "_rec.yuv")]
     out = {}
-    for tag, env in (("serial", _env(MLTCNN_WEIGHTS_DIR=wdir)), ("batch", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log))):
+    # "batch2": the same through ONE predictor over two device contexts (MLTCNN_DEVICES: mlt_config.devices[], batched CUs dealt round-robin;
+    # both on ordinal 0 here -- a 1-GPU box -- the path an 8-GPU node takes with MLTCNN_DEVICES=0,1,...,7)
+    for tag, env in (("serial", _env(MLTCNN_WEIGHTS_DIR=wdir)), ("batch", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)),
+                     ("batch2", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_DEVICES="0,0"))):
         r = subprocess.run(cmd(tag), env=env, capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "error" not in r.stderr and r.stdout.count("Hello") == 0, r.stderr[-2000:]
         out[tag] = hashlib.sha256(open(os.path.join(tmp, tag + ".bin"), "rb").read()).hexdigest()
-    assert out["serial"] == out["batch"], out
+    assert out["serial"] == out["batch"] == out["batch2"], out
     sizes = [int(l.split()[7]) for l in open(log)]
     print(f"probe and replay on the GPU: {len(sizes)} batches over {FRAMES - 1} inter pictures, sizes {sorted(set(sizes))}, {sum(sizes)} CUs; bitstream == serial")
     assert max(sizes) >= 3 and sum(sizes) == (FRAMES - 1) * 32

@@ -7,7 +7,7 @@ What the patch does (reference lines):
   source/Lib/EncoderLib/EncCu.cpp:60-65     drop <torch/script.h> / OpenCV includes, include host/mlt_split_predictor.hpp
   source/Lib/EncoderLib/EncCu.cpp:160-206   EncCu::destroy  -> delete the predictor (mlt_shutdown)
   source/Lib/EncoderLib/EncCu.cpp:233-259   EncCu::init     -> create the predictor ONCE (weights dir / device / size mask from
-                                            MLTCNN_WEIGHTS_DIR / MLTCNN_DEVICE / MLTCNN_SIZE_MASK / MLTCNN_FLAGS; the reference re-loads the .pt per CU, :894-900)
+                                            MLTCNN_WEIGHTS_DIR / MLTCNN_DEVICE(S) / MLTCNN_SIZE_MASK / MLTCNN_FLAGS; the reference re-loads the .pt per CU, :894-900)
   source/Lib/EncoderLib/EncCu.cpp:746-756   gate            -> SplitPredictor::gate (same condition, size mask instead of the commented-out clauses)
   source/Lib/EncoderLib/EncCu.cpp:801-927   gather / absdiff / normalise / tensor assembly / jit::load / forward / argmax
                                             -> ONE call: predictSplitMode(org buf+stride, pred buf+stride, cuw, poc, qp)
@@ -65,9 +65,18 @@ def patch_enccu_cpp(t):
                      "        const char *dev  = std::getenv( \"MLTCNN_DEVICE\" );\n"
                      "        const char *mask = std::getenv( \"MLTCNN_SIZE_MASK\" );     // MLT_SIZE_* bits; default: 128x128 only\n"
                      "        const char *flg  = std::getenv( \"MLTCNN_FLAGS\" );         // MLT_FLAG_* bits; default: the decision guard (split modes are what the encoder consumes)\n"
+                     "        const char *devs = std::getenv( \"MLTCNN_DEVICES\" );       // \"0,1,2,...\": ONE predictor over several GPUs (batched CUs are dealt round-robin)\n"
+                     "        int devList[MLT_MAX_DEVICES], numDev = 0;\n"
+                     "        for( const char *p = devs; p && *p && numDev < MLT_MAX_DEVICES; )\n"
+                     "        {\n"
+                     "            char *end = nullptr;\n"
+                     "            devList[numDev++] = (int) std::strtol( p, &end, 10 );\n"
+                     "            p = ( end && *end == ',' ) ? end + 1 : nullptr;\n"
+                     "        }\n"
                      "        m_cnnSplitPredictor = new mlt::SplitPredictor( dir ? dir : \"./torch_model\", dev ? std::atoi( dev ) : 0,\n"
                      "                                                     mask ? (uint32_t) std::strtoul( mask, nullptr, 0 ) : MLT_SIZE_128,\n"
-                     "                                                     flg ? (uint32_t) std::strtoul( flg, nullptr, 0 ) : MLT_FLAG_DECISION_GUARD );\n"
+                     "                                                     flg ? (uint32_t) std::strtoul( flg, nullptr, 0 ) : MLT_FLAG_DECISION_GUARD,\n"
+                     "                                                     numDev ? devList : nullptr, numDev );\n"
                      "    }\n\n}\n", "init")
     t = cut(t, "if (partitioner.chType == 0 && tempCS->slice->getSliceType() != I_SLICE)", "useCNN = true;",
             "        if (m_cnnSplitPredictor && m_cnnSplitPredictor->ok())\n"
