@@ -48,6 +48,7 @@ struct ConvArgs {
   int gap_slots, gap_l;
   // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
+  int lo8_scale;               // NSPLIT == 5 (hi fp16 + FP8 lo plane): E8M0 scale byte of the lo plane, replicated (mlt_model.h: lo8_exp)
 };
 
 struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma, lat, gt_w2; };  // gt_w2 (exact packing only): taps per weight step of the hi+lo-WEIGHTS tier (NSPLIT = 3)  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup
@@ -98,6 +99,7 @@ struct StemBlockArgs {
 struct ChainConv {
   const void *w;       // packed fp16 weights (same packing as the stand-alone conv of this layer)
   size_t w_lo_off;     // hi+lo-weights form (chain_kernel<..., W2>): byte offset of the lo plane
+  int lo8_scale;       // ... with an FP8 lo plane (LO8): the E8M0 scale byte 127 - lo8_exp, replicated into all four bytes
   const float *bias;   // folded BN bias
   float acc_scale;
   int relu;

@@ -164,6 +164,34 @@ __device__ __forceinline__ int quad_flat_bits(uint32_t w0, uint32_t w1, uint32_t
   return (near ? 1 : 0) | (exact ? 2 : 0);
 }
 
+// ---- FP8 lo products (round 4; hi+lo-weights forms on 64-channel chunks) ----
+// The lo product of a (tap, 64-channel chunk) is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, twice the fp16 rate): its A operand is
+// the FP8 lo plane (mlt_model.cpp: byte j of lane (r, h) = lo[cout r][cin 32 h + j]), its B operand channels 32 h .. 32 h + 31 of the lane's
+// pixel from an e4m3 image of the activation (two ds_read_b128).  Lane (x, h) of A meets lane (y, h) of B byte for byte (probed with exact
+// integer data: scripts/probes/f8_mfma_layout_probe.hip), so any channel order works as long as both operands use the same one.
+typedef int int8v __attribute__((ext_vector_type(8)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+// 8 fp16 activations (>= 0: every chain input is a ReLU output) -> 8 e4m3 bytes (2 dwords), clamped to e4m3's largest finite value
+__device__ __forceinline__ void cvt_frag_fp8(const half8 &v, uint32_t &d0, uint32_t &d1) {
+  const half2v top = {(_Float16)448, (_Float16)448};
+  const half2v *h = (const half2v *)&v;
+  short2v r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_elementwise_min(h[0], top), 1.0f, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_elementwise_min(h[1], top), 1.0f, true);
+  d0 = *(uint32_t *)&r;
+  short2v q = {0, 0};
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_elementwise_min(h[2], top), 1.0f, false);
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_elementwise_min(h[3], top), 1.0f, true);
+  d1 = *(uint32_t *)&q;
+}
+__device__ __forceinline__ float16v mfma_lo8(const half8 &a_lo, const half8 &a_hi, const half8 &b_lo, const half8 &b_hi, const float16v &c, int scale_a) {
+  int8v a, b;
+  const uint32_t *pl = (const uint32_t *)&a_lo, *ph = (const uint32_t *)&a_hi, *ql = (const uint32_t *)&b_lo, *qh = (const uint32_t *)&b_hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a[e] = (int)pl[e]; a[4 + e] = (int)ph[e]; b[e] = (int)ql[e]; b[4 + e] = (int)qh[e]; }
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, 0x7F7F7F7F);  // fp8 x fp8; A scaled by 2^-lo8_exp, B by 1
+}
+
 // ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------
 // After a 32x32 MFMA lane l = (p, h) holds, per register quad q, output channels 8q+4h .. 8q+4h+3 of pixel p, so
 // lanes p and p+32 own the two 8-byte halves of one 16-byte span.  v_permlane32_swap exchanges the upper half-wave
@@ -244,7 +272,9 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
   const int patch_lds = (DMA ? 2 : (NSPLIT == 2 ? 2 : 1)) * a.patch_bytes;
-  const int lds = patch_lds + NBUF * (NSPLIT >= 2 ? 2 : 1) * GT * (KC / 16) * CBT * 1024 + extra_lds;
+  // (NSPLIT == 5: + the FP8 lo plane of every ring step and the e4m3 copy of the patch, 80 bytes per pixel of the fp16 patch's KC * 2 + 16)
+  const int patch8 = NSPLIT == 5 ? ((a.patch_bytes / (KC * 2 + 16) + 1) * (KC + 16) + 1023) / 1024 * 1024 : 0;
+  const int lds = patch_lds + NBUF * ((NSPLIT == 2 || NSPLIT == 3 ? 2 : 1) * GT * (KC / 16) * CBT * 1024 + (NSPLIT == 5 ? GT * CBT * 2048 : 0)) + patch8 + extra_lds;
   static DeviceOnce once;
   if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -494,9 +524,10 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
     // its bit-identical per-conv form: (chunk, tap, k-step, hi, lo) per accumulator.
     if (stride == 1 && cin == cout && cin >= 64) {
       if (variant != MLT_CONV_LATENCY) return hipErrorInvalidValue;
-      if (cin == 64) return launch_conv_t<64, 64, 1, 9, false, 64, 3, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);
-      if (cin == 128) return launch_conv_t<128, 128, 1, 9, false, 64, 3, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
-      if (cin == 256) return launch_conv_t<256, 256, 1, 9, false, 64, 3, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+      // (NSPLIT = 5: hi fp16 plane + FP8 lo plane, the packing of these layers in the MLT_MODEL_W2 model)
+      if (cin == 64) return launch_conv_t<64, 64, 1, 9, false, 64, 3, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);   // (fp16 lo plane: see mlt_model.cpp)
+      if (cin == 128) return launch_conv_t<128, 128, 1, 9, false, 64, 5, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
+      if (cin == 256) return launch_conv_t<256, 256, 1, 9, false, 64, 5, 1, 1, 1, 4, 3, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);
       return hipErrorInvalidValue;
     }
     if (variant != MLT_CONV_DEFAULT) return hipErrorInvalidValue;
@@ -620,12 +651,13 @@ hipError_t mlt_launch_chain(int c, int h, bool with_s2, bool oob_zero, bool w2, 
   static DeviceOnce once[13];
   if (w2) {  // hi+lo-weights forms (MLT_MODEL_W2 packing: the fast tiling, two planes): one tap per ring step, conv padding from beyond the LDS only
     if (!oob_zero || with_s2 || a.nconv != 3) return hipErrorInvalidValue;
-    if (c == 64 && h == 32)   // 128 KiB sample + 2 x (2 planes x 8 KiB)
-      return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 2, 1, 2, 3, true, false, false, true, true>, once[10], a, grid_x, 512, 128 * 1024 + 2 * 16 * 1024, st);
-    if (c == 128 && h == 16)  // 64 KiB sample + 3 x (2 planes x 16 KiB)
-      return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 1, CFG_CHAINW2_RB, 1, 2, 3, true, false, true, true, true>, once[11], a, grid_x, 512, 64 * 1024 + CFG_CHAINW2_RB * 32 * 1024, st);
-    if (c == 256 && h == 8)
-      return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 1, CFG_CHAINW2_RB, 1, 2, 3, true, false, true, true, true>, once[12], a, grid_x, 512, 64 * 1024 + CFG_CHAINW2_RB * 32 * 1024, st);
+    // ring step = hi fp16 plane + FP8 lo plane (LO8): 8 + 4 KiB per tap (64 channels), 16 + 8 KiB (128 / 256)
+    if (c == 64 && h == 32)   // 128 KiB sample + 2 steps of two fp16 planes (8 + 8 KiB)
+      return launch_chain_t(chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 2, 1, 2, 3, true, false, false, true, true, false>, once[10], a, grid_x, 512, 128 * 1024 + 2 * 16 * 1024, st);
+    if (c == 128 && h == 16)  // 64 KiB sample + 2 ring steps + the 32 KiB e4m3 image of the sample
+      return launch_chain_t(chain_kernel<128, 4, 0, 2, 2, 2, 4, 1, 2, 1, 2, 3, true, false, true, true, true, true>, once[11], a, grid_x, 512, (64 + 2 * 24 + 32) * 1024, st);
+    if (c == 256 && h == 8)   // (64 KiB sample + 2 ring steps + the 32 KiB e4m3 image of the sample)
+      return launch_chain_t(chain_kernel<256, 3, 1, 2, 1, 2, 4, 1, 2, 1, 2, 3, true, false, true, true, true, true>, once[12], a, grid_x, 512, (64 + 2 * 24 + 32) * 1024, st);
     return hipErrorInvalidValue;
   }
   // oob_zero: conv padding from DS reads beyond the LDS allocation (the probed default) or from zero masks; the kernels off the default path

@@ -64,6 +64,30 @@ float f16_to_f32(uint16_t hbits) {
   return f;
 }
 
+// OCP FP8 e4m3fn (bias 7, no infinities, max 448, subnormal step 2^-9): round to nearest even, saturating
+static uint8_t f32_to_e4m3(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint8_t sign = (uint8_t)((x >> 24) & 0x80u);
+  float a = std::fabs(f);
+  if (!(a == a)) return (uint8_t)(sign | 0x7Fu);
+  if (a >= 448.f) return (uint8_t)(sign | 0x7Eu);  // saturate to the largest finite value
+  if (a < 0.0009765625f) return sign;               // below half the smallest subnormal (2^-10): zero
+  int e;
+  const float m = std::frexp(a, &e);                // a = m * 2^e, m in [0.5, 1)
+  int exp = e - 1;                                  // a = (2m) * 2^exp, 2m in [1, 2)
+  if (exp < -6) {                                   // subnormal: multiples of 2^-9
+    const float q = std::nearbyint(a * 512.f);      // (default rounding mode: to nearest even)
+    const int qi = (int)q;
+    return (uint8_t)(sign | (qi >= 8 ? 0x08u : (uint8_t)qi));
+  }
+  float frac = (2.f * m - 1.f) * 8.f;               // 3 mantissa bits
+  int qi = (int)std::nearbyint(frac);
+  if (qi == 8) { qi = 0; ++exp; }
+  if (exp > 8 || (exp == 8 && qi > 6)) return (uint8_t)(sign | 0x7Eu);
+  return (uint8_t)(sign | ((exp + 7) << 3) | qi);
+}
+
 #pragma pack(push, 1)
 struct BlobHead { char magic[4]; uint32_t version, arch, n; };
 struct BlobEntry { char name[64]; uint32_t ndim, dims[4]; uint64_t off, numel; };
@@ -108,7 +132,10 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
   pc.plane_halves = (size_t)cout * cin * tt;
   const bool two = pc.exact || pc.w2;  // (hi, lo) planes, plain rounding
-  pc.w.assign(pc.plane_halves * (two ? 2 : 1), 0);
+  // the layers the 128- and 256-channel chain_kernel<..., W2, LO8> stream: FP8 lo plane (see mlt_model.h).  The 64-channel chain keeps an fp16 lo
+  // plane: a wave owns 128 pixels there (8 accumulators), and the e4m3 copy of four pixel blocks' fragments does not fit its registers (284 B of scratch)
+  pc.lo8 = pc.w2 && KC == 64 && !w_sc && cin >= 128;
+  pc.w.assign(pc.lo8 ? pc.plane_halves + pc.plane_halves / 2 : pc.plane_halves * (two ? 2 : 1), 0);
   // power-of-two storage scale: largest 2^s <= 2^6 keeping every stored weight below 2^12
   double wmax = 1e-30;
   for (int co = 0; co < cout; ++co) {
@@ -132,6 +159,14 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
       hi_slot = q;
     }
   };
+  std::vector<double> lo8v;  // lo8: the exact lo residuals, encoded after their common scale is known
+  if (pc.lo8) lo8v.assign((size_t)cout * cin * tt, 0.0);
+  auto put8 = [&](uint16_t &hi_slot, double exact_unscaled, size_t flat) {
+    const double exact = exact_unscaled * wmul;
+    const uint16_t q = f32_to_f16((float)exact);
+    hi_slot = q;
+    lo8v[flat] = exact - (double)f16_to_f32(q);
+  };
   for (int co = 0; co < cout; ++co) {
     const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
     for (int ci = 0; ci < cin; ++ci) {
@@ -140,9 +175,31 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
         return pc.w[((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j];
       };
       double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of this (co, ci)
+      if (pc.lo8) {
+        for (int t = 0; t < taps; ++t) put8(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], ((size_t)co * cin + ci) * tt + t);
+        continue;
+      }
       for (int t = 0; t < taps; ++t) put(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], err);
       double err_sc = 0.0;
       if (w_sc) put(at(taps), (double)w_sc[(size_t)co * cin + ci] * scale_sc[co], err_sc);
+    }
+  }
+  if (pc.lo8) {
+    double lomax = 1e-30;
+    for (double v : lo8v) lomax = std::max(lomax, std::fabs(v));
+    pc.lo8_exp = (int)std::floor(std::log2(224.0 / lomax));  // largest residual -> [112, 224]: inside e4m3's range (max 448) with headroom
+    if (pc.lo8_exp > 60) pc.lo8_exp = 60;
+    const double mul8 = std::ldexp(1.0, pc.lo8_exp);
+    uint8_t *lo = (uint8_t *)(pc.w.data() + pc.plane_halves);
+    for (int co = 0; co < cout; ++co) {
+      const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
+      for (int ci = 0; ci < cin; ++ci) {
+        const int chunk = ci / KC, kk = ci % KC, hh = kk / 32, jb = kk % 32;  // channel kk of the chunk <-> byte jb of lane half hh
+        for (int t = 0; t < tt; ++t)
+          // fragment = [16-byte half of the lane's 32 bytes][lane][16 bytes]: two lane-linear (conflict-free) ds_read_b128 per lane
+          lo[((((size_t)(ctile * NCHUNK + chunk) * tt + t) * CBT + cbt) * 2048) + (size_t)(jb >> 4) * 1024 + (size_t)(hh * 32 + r) * 16 + (jb & 15)] =
+              f32_to_e4m3((float)(lo8v[((size_t)co * cin + ci) * tt + t] * mul8));
+      }
     }
   }
 }

@@ -20,6 +20,11 @@ struct PackedConv {
   int dma = 0, mt_dma = 0;             // LDS-DMA staging variant (0 none, 1 resident weights, 2 weight ring) and its pixels per workgroup
   bool has_sc = false;
   bool exact = false;          // w holds a hi plane followed by a lo plane (fp16 pair per weight)
+  bool lo8 = false;            // w2 layers with 64-channel chunks (stride 1, >= 64 channels): the lo plane is FP8 (OCP e4m3), packed as the A operand of
+                               // v_mfma_scale_f32_32x32x64_f8f6f4 -- [cout tile][chunk][tap][32-ch block][16-byte half][lane 64][16 bytes], byte j of lane 32h + r =
+                               // lo[cout r][cin = 32 h + j of the chunk] * 2^lo8_exp -- half the bytes of an fp16 lo plane, and the lo
+                               // product of a (tap, chunk) is ONE MFMA at twice the fp16 rate (a 2^-11-relative correction tolerates a 3-bit mantissa)
+  int lo8_exp = 0;             // the MFMA's block scale undoes it (E8M0 byte 127 - lo8_exp)
   bool w2 = false;             // hi+lo-WEIGHTS tier on the FAST tiling (kc / ct / gt of the single-pass kernels): two planes like `exact`, read by the
                                // W2 forms of the fused kernels (chain_kernel, stem_block_kernel, block32_kernel) and by conv_mfma_kernel<NSPLIT = 3>
   size_t plane_halves = 0;     // halves per plane

@@ -13,13 +13,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
-STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s, false>"
-STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s, false>"
-CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 2, 2, 1, 2, 3, true, false, false, %s, false>"
+STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s, false, false>"
+STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 3, 2, 2, 2, 3, true, true, true, %s, false, false>"
+CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 2, 2, 1, 2, 3, true, false, false, %s, false, false>"
 # hi+lo-weights forms (round 4): two weight planes per ring step, no stride-2 front conv, padding from beyond the LDS only
-W2_STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 1, 3, 1, 2, 3, true, false, true, true, true>"
-W2_STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 1, 3, 1, 2, 3, true, false, true, true, true>"
-W2_CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 2, 1, 2, 3, true, false, false, true, true>"
+W2_STAGE_128 = "chain_kernel<128, 4, 0, 2, 2, 2, 4, 1, 2, 1, 2, 3, true, false, true, true, true, true>"
+W2_STAGE_256 = "chain_kernel<256, 3, 1, 2, 1, 2, 4, 1, 2, 1, 2, 3, true, false, true, true, true, true>"
+W2_CHAIN_64 = "chain_kernel<64, 5, 0, 2, 4, 1, 8, 1, 2, 1, 2, 3, true, false, false, true, true, false>"
 FORMS = ("true", "false")  # conv padding from beyond the LDS (the probed default) / from zero masks (fallback)
 
 
