@@ -370,18 +370,19 @@ def main():
     exact = tier == 1
     arith = m.arithmetic(size)
     stages = "+".join(f"layer{i}" for i in range(4) if (int(arith["w2_stages"]) >> i) & 1)
+    xstages = "+".join(f"layer{i}" for i in range(4) if (int(arith["x_stages"]) >> i) & 1)
     out = {
         "metric": f"CU-inferences/sec (batch {B}, {size}x{size})", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else f"f16, weights hi+lo in {stages} (fp32 accumulate)" if tier == 3 else "f16 (fp32 accumulate)", "data": "synthetic",
+        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else f"f16, weights hi+lo in {stages} (fp32 accumulate)" if tier == 3 else f"f16x2 pairs in {xstages}, f16 with weights hi+lo in {stages or 'no stage'} (fp32 accumulate)" if tier == 4 else "f16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if size == 128 else 2}]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
                    "batch_per_gpu": B, "cu_size": size, "weights": f"synthetic seed {args.weight_seed} (no trained checkpoint is distributed)",
                    "parallelism": f"shard{world}",
-                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
-                                  "w2_stages": int(arith["w2_stages"]), "decision_guard_margin": arith["guard_margin"],
+                                  "w2_stages": int(arith["w2_stages"]), "x_stages": int(arith["x_stages"]), "decision_guard_margin": arith["guard_margin"],
                                   "guard_reruns_total": arith["guard_reruns"], "guard_reruns_per_step": round(reruns_per_step, 2),
                                   "guard_rerun_fraction": round(reruns_per_step / B, 5)},
                    "content": args.content if args.flat_frac == 0 else f"{args.content} + {args.flat_frac:g} flat / dither / ramp / low-contrast CUs"},

@@ -118,7 +118,8 @@ mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
  * otherwise the 128 model tries the middle tiers the same way -- (hi, lo) pairs for the WEIGHTS only (hi fp16; lo fp16, or e4m3 with a
  * per-layer power-of-two scale where the layer has >= 128 input channels: the lo term carries < 2^-11 of the product), on the W2 forms
  * of the fused kernels, in a SUBSET of the four stages: the 15 subsets are priced in the order of
- * their measured cost and the cheapest one that meets the contract is kept (mlt_arith_info.w2_stages) -- and a size that
+ * their measured cost and the cheapest one that meets the contract is kept (mlt_arith_info.w2_stages); failing those, the tiers that
+ * put one to three stages into the exact arithmetic and the others into (hi, lo) weights (.x_stages), cheapest first -- and a size that
  * meets the contract with none of them runs exact (mlt_arithmetic reports the outcome).  The
  * admission is STATISTICAL (synthetic content, Gaussian-tail factor), not a bound: "within 1e-3" is calibrated, not proven. */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
@@ -126,7 +127,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 /* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
 typedef struct mlt_arith_info {
   int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations in
-                             every stage; 3: (hi, lo) weights in SOME stages (w2_stages), single pass in the others */
+                             every stage; 3: (hi, lo) weights in SOME stages (w2_stages), single pass in the others; 4: the exact arithmetic in the
+                             stages of x_stages, (hi, lo) weights in the others (w2_stages) */
   int32_t calibrated;     /* 1: the calibration ran for this size */
   float calib_rms, calib_max; /* |dlogit| of the chosen non-exact tier (or of the fast one if exact was chosen) vs exact over the calibration CUs:
                                  worst rms pooled per content class / per head, and the overall maximum */
@@ -134,6 +136,8 @@ typedef struct mlt_arith_info {
   uint64_t guard_reruns;  /* CUs re-evaluated by the guards since init */
   int32_t w2_stages;      /* ABI 3: bit s set = layer s (0..3) runs (hi, lo) weights; 0 for the fast and the exact arithmetic */
   float guard_margin;     /* ABI 3: the decision guard's threshold in effect for this size (0 when the guard is off) */
+  int32_t x_stages;       /* ABI 3: bit s set = layer s runs the exact arithmetic inside a mixed tier (exact == 4); 0 otherwise */
+  int32_t reserved;
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 
