@@ -328,7 +328,16 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   if (pc.stride == 2 && tw == 8 && (2 * half) % 4 != 2) ++half;
   int rp = pc.stride == 2 ? 2 * half : pw;
   if (pc.stride == 1 && tw == 8) while (rp % 4 != 2) ++rp;
-  while (spw > 1 && (size_t)spw * ph * rp * PS * act_planes > 64 * 1024) spw /= 2;
+  // LDS budget of the patch planes: 64 KiB -- or, for the exact arithmetic (two planes), what the two-deep weight ring of the tiling leaves of the
+  // 160 KiB (round 4: the 128 -> 256 stride-2 layer on 8 x 8 maps needs 96 KiB for TWO samples per tile; with one, half of the tile's waves idled)
+  size_t patch_budget = 64 * 1024;
+  if (nsplit == 2) {
+    const int tt = pc.taps + (pc.has_sc ? 1 : 0), nbuf = tt / pc.gt > 1 ? 2 : 1;
+    const size_t ring = (size_t)nbuf * 2 * pc.gt * (pc.kc / 16) * (pc.ct / 32) * 1024;
+    static const bool big = tuning_env("MLT_EXACT_PATCH_64K") == nullptr;
+    if (big && ring + 64 * 1024 < 160 * 1024) patch_budget = 160 * 1024 - ring;
+  }
+  while (spw > 1 && (((size_t)spw * ph * rp * PS + 1023) / 1024 * 1024) * act_planes > patch_budget) spw /= 2;
   a.tw_l = ilog2(tw); a.th_l = ilog2(th); a.spw_l = ilog2(spw);
   a.ph = ph; a.pw = pw; a.rp = rp; a.half = half;
   auto magic = [](int d) { return d < 2 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); };  // 0 encodes d == 1 (1x1 convs on 1x1 maps)

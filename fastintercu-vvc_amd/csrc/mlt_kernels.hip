@@ -339,6 +339,17 @@ static hipError_t launch_ring_dma_t(const ConvArgs &a, int grid_x, hipStream_t s
 #ifndef CFG_GTE_S2   // round 4 sweep (profiles/r04h_sweep_exact*.txt): 2 taps per step -> 128->256 s2 1.57 -> 1.25 ms, 32->64 s2 1.46 -> 1.33 ms (exact 128 model
 #define CFG_GTE_S2 2 // +2 %), 64x64 model 958 k -> 1.00 M CU/s, 16x16 +3 %; 5 taps do not fit the LDS beside two activation planes
 #endif
+#ifndef CFG_UNE_32   // exact arithmetic: patch items per lane prefetched in registers (two planes each); a patch with more items per lane takes a
+#define CFG_UNE_32 5  // synchronous tail at the top of the tile (the 128 model's tiles have 4.4 - 4.8 items per lane: phase stamps, commit 36 - 45 %);
+                      // round 4 sweep (profiles/r04m_sweep_exact_prefetch.txt): 32 -> 32 1.57 -> 1.49 ms, 32 -> 64 s2 1.33 -> 1.27; the 64 / 128-channel
+                      // stride-2 layers LOSE with 5 (1.02 -> 1.09, 0.84 -> 0.87) and keep 3
+#endif
+#ifndef CFG_UNE_64
+#define CFG_UNE_64 3
+#endif
+#ifndef CFG_UNE_S2
+#define CFG_UNE_S2 3
+#endif
 #ifndef CFG_BIG_WP_EXACT  // ... exact arithmetic (small-CU models, maps of 1..16 pixels): 128-pixel tiles, 8 waves
 #define CFG_BIG_WP_EXACT 4
 #endif
@@ -585,12 +596,12 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
     if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 3, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 2, 5, 1, false>(a, grid_x, extra_lds, st);
     if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 3, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, 2, 5, 1, false>(a, grid_x, extra_lds, st);
   }
-  CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, 3, CFG_32_MINW)
-  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, CFG_3264_UN, 3, CFG_32_MINW)
-  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, CFG_GTE_S1, CFG_S1_RB, 2, 6, 3, CFG_S1_MINW)
-  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_GTE_S2, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE(32, 32, 1, false, 32, 32, 1, CFG_32_WPB, 1, CFG_32_WP, 9, 3, 1, 2, 5, CFG_UNE_32, CFG_32_MINW)
+  CONV_CASE(32, 64, 2, true, 32, 32, CFG_3264_WCB, 1, CFG_3264_WC, CFG_3264_WP, CFG_3264_GT, CFG_GTE_S2, CFG_3264_RB, 2, CFG_3264_UN, CFG_UNE_32, CFG_32_MINW)
+  CONV_CASE(64, 64, 1, false, 64, 32, CFG_64_WCB, CFG_64_WPB, CFG_64_WC, CFG_64_WP, CFG_64_GT, CFG_GTE_S1, CFG_S1_RB, 2, 6, CFG_UNE_64, CFG_S1_MINW)
+  CONV_CASE(64, 128, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, 2, CFG_GTE_S2, 2, 2, 5, CFG_UNE_S2, CFG_S2_MINW)
   CONV_CASE2(128, 128, 1, false, 64, 32, CFG_BIG_WCB, CFG_128_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, CFG_GTE_S1, CFG_S1_RB, 2, 3, 2, CFG_S1_MINW)
-  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, CFG_GTE_S2, 2, 2, 5, 3, CFG_S2_MINW)
+  CONV_CASE(128, 256, 2, true, 32, 32, CFG_S2BIG_WCB, CFG_S2BIG_WPB, CFG_S2BIG_WC, CFG_S2BIG_WP, CFG_S2B_GT, CFG_GTE_S2, 2, 2, 5, CFG_UNE_S2, CFG_S2_MINW)
   CONV_CASE2(256, 256, 1, false, 64, 32, CFG_BIG_WCB, CFG_BIG_WPB, CFG_BIG_WC, CFG_BIG_WP, CFG_BIG_WP_EXACT, CFG_BIG_GT, CFG_GTE_S1, CFG_S1_RB, 2, 4, 2, CFG_S1_MINW)
   CONV_CASE(64, 96, 2, true, 32, 32, 3, 1, 1, 4, 1, CFG_GTE_S2, 2, 2, 5, 3, 1)
   CONV_CASE(96, 96, 1, false, 32, 32, 3, 1, 1, 4, 3, CFG_GTE_S1, 2, 2, 3, 2, 1)

@@ -12,10 +12,11 @@ VDIR = os.path.join(ROOT, "fastintercu-vvc_amd", "_variants")
 VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); run each twice for box noise
     "base": [],
     # round 4: taps per weight step of the exact arithmetic's per-conv kernels (SWEEP_ARGS="--weight-seed 22" = the exact 128 model, "--size 64")
-    "gte_s2_2": ["CFG_GTE_S2=2"],
-    "gte_s2_5": ["CFG_GTE_S2=5"],
-    "gte_s1_3": ["CFG_GTE_S1=3"],
-    "gte_s2_2_s1_3": ["CFG_GTE_S2=2", "CFG_GTE_S1=3"],
+    # (gte_s2_2 / gte_s2_5 / gte_s1_3: profiles/r04h_sweep_exact*.txt -- CFG_GTE_S2 = 2 became the default)
+    # patch items per lane prefetched in registers, exact arithmetic (phase stamps: the synchronous tail of the commit is 36 - 45 % of the 32-channel launches)
+    "une_5": ["CFG_UNE_32=5", "CFG_UNE_S2=5"],
+    "une_5_all": ["CFG_UNE_32=5", "CFG_UNE_S2=5", "CFG_UNE_64=5"],
+    "une_6": ["CFG_UNE_32=6", "CFG_UNE_S2=6"],
 }
 # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
 #   "s2_wp8": ["CFG_3264_WP=8"], "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"]
