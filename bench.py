@@ -369,8 +369,8 @@ def main():
     tier = int(arith["exact"])  # 0 fast, 1 exact, 2 hi+lo weights on fp16 activations in every stage, 3 in the stages of w2_stages only
     exact = tier == 1
     arith = m.arithmetic(size)
-    stages = "+".join(f"layer{i}" for i in range(4) if (int(arith["w2_stages"]) >> i) & 1)
-    xstages = "+".join(f"layer{i}" for i in range(4) if (int(arith["x_stages"]) >> i) & 1)
+    stages = "+".join(f"layer{i}" for i in range(5) if (int(arith["w2_stages"]) >> i) & 1)
+    xstages = "+".join(f"layer{i}" for i in range(5) if (int(arith["x_stages"]) >> i) & 1)
     out = {
         "metric": f"CU-inferences/sec (batch {B}, {size}x{size})", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -58,6 +58,8 @@ struct SizeState {
                                // ACTIVATION rounding, spread evenly over all 18 rounding sites, misses the contract by a few per cent
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
+  bool small_mix = false;      // 64 / 32 / 16 (round 4): configured exact, but the load-time calibration may keep the first stages -- the large maps, where the
+                               // time is -- on the single-pass kernels (x_mask = the remaining stages); exact when no prefix meets the contract
   bool calibrated = false;
   float calib_rms = 0.f, calib_max = 0.f;
   uint64_t reruns = 0;         // CUs re-evaluated by the guards
@@ -1034,7 +1036,9 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   std::string err;
   mlt::Model m;
-  if (!mlt::build_model(blob, bytes, st.want_exact ? mlt::MLT_MODEL_EXACT : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  static const bool no_small_mix = tuning_env("MLT_NO_SMALL_MIX") != nullptr;
+  const bool small_mix = st.small_mix && !no_small_mix;   // (then: fast copy = `model`, exact copy = `model_exact`, the calibration picks the stages)
+  if (!mlt::build_model(blob, bytes, (st.want_exact && !small_mix) ? mlt::MLT_MODEL_EXACT : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
   if (st.head_index < 0 || st.head_index >= m.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
   // a reload replaces device buffers that captured graphs and in-flight work point to
@@ -1044,7 +1048,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   // error path below releases what it uploaded, so a failed reload leaves the size cleanly unloaded instead of leaking)
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
   st.loaded = false;
-  st.exact = st.want_exact;
+  st.exact = st.want_exact && !small_mix;
   st.w2 = false; st.w2_mask = 0; st.x_mask = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
@@ -1057,11 +1061,53 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   };
   int rc = upload_model(ctx, st.model);
   if (rc) return fail(rc);
-  if (!st.exact && (st.flat_guard || st.margin_guard || st.calibrate)) {
+  if (!st.exact && (st.flat_guard || st.margin_guard || st.calibrate || small_mix)) {
     mlt::Model me;
     if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_EXACT, size, me, err)) { ctx->err = "weights (exact copy): " + err; return fail(MLT_ERR_WEIGHTS); }
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return fail(rc);
+    if (small_mix) {
+      // The small models (maps of 1 .. 32 pixels) miss the contract in the single pass -- but their time is in the FIRST stages (the
+      // large maps: layer0 + layer1 are 65 % of the 64 x 64 model's exact step) and their error in the LAST ones (nothing for the pooling
+      // to average on 1 .. 16 pixels).  Candidates: the single pass in stages 0 .. k-1, the exact arithmetic from stage k on, longest
+      // prefix (cheapest) first; the admission rule of the 128 model.  No prefix -> exact.
+      CalibSession cal(ctx, st);
+      if ((rc = cal.begin())) return fail(rc);
+      const int ns = st.model.n_stages;
+      const unsigned all = (1u << ns) - 1u;
+      static const char *force_k = tuning_env("MLT_SMALL_PREFIX");
+      bool ok = false;
+      auto within = [&]() {
+        const float kk = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
+        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance;
+      };
+      static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
+      for (int k = ns - 1; k >= 1 && !ok; --k) {
+        if (force_k) k = std::atoi(force_k) < 1 ? 1 : std::atoi(force_k) > ns - 1 ? ns - 1 : std::atoi(force_k);
+        const unsigned pre = (1u << k) - 1u, xm = all & ~pre;
+        if ((rc = cal.price(0, xm))) return fail(rc);
+        ok = within() || force_k != nullptr;
+        if (ok) st.x_mask = xm;
+        if (!ok && !no_w2 && k == 1) {  // ... layer0 with hi+lo WEIGHTS (the single pass's weight rounding removed; the fused layer0 kernels on 32 x 32 maps)
+          if (!st.model_w2.on_device) {
+            mlt::Model mw;
+            if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
+            st.model_w2 = std::move(mw);
+            if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
+          }
+          if ((rc = cal.price(pre, xm))) return fail(rc);
+          if ((ok = within())) { st.x_mask = xm; st.w2_mask = pre; st.w2 = true; }
+        }
+        if (force_k) break;
+      }
+      if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
+      if (!ok) {  // run it exact
+        free_model(st.model);
+        st.model = std::move(st.model_exact);
+        st.model_exact = mlt::Model();
+        st.exact = true;
+      }
+    }
     if (st.calibrate) {
       CalibSession cal(ctx, st);
       if ((rc = cal.begin())) return fail(rc);
@@ -1153,9 +1199,9 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->w2 ? (st->x_mask ? 4 : st->w2_mask != 0xFu ? 3 : 2) : 0;
+  out->exact = st->exact ? 1 : st->x_mask ? 4 : st->w2 ? (st->w2_mask != 0xFu ? 3 : 2) : 0;
   out->w2_stages = st->w2 ? (int32_t)st->w2_mask : 0;
-  out->x_stages = st->w2 ? (int32_t)st->x_mask : 0;
+  out->x_stages = st->exact ? 0 : (int32_t)st->x_mask;
   out->reserved = 0;
   out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
@@ -1227,6 +1273,7 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
     st.flat_guard = (cfg->flags & MLT_FLAG_NO_FLAT_GUARD) == 0;
     // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
     st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
+    st.small_mix = sizes[i] != 128 && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];

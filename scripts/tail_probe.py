@@ -37,7 +37,7 @@ def main():
         m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob})
         e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128)
         ar = m.arithmetic(size)
-        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 mixed, 2 hi+lo weights, 1 exact), calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
+        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 hi+lo weights in stages 0x{ar['w2_stages']:x}, 2 hi+lo weights everywhere, 4 exact in stages 0x{ar['x_stages']:x} + hi+lo weights in 0x{ar['w2_stages']:x}, 1 exact), calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
         tot_n = tot_bad = 0
         worst = 0.0
         for name, _ in classes:

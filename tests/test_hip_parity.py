@@ -402,6 +402,46 @@ def test_middle_tier_hi_lo_weights(gpu):
         m.close()
 
 
+def test_small_models_calibrated_prefix(gpu):
+    """Round 4: the 64 / 32 / 16 models are configured exact, but the load-time calibration may keep layer0 (the largest maps, where their
+    time is) on the single-pass or the hi+lo-weights kernels when the 1e-3 contract still holds (mlt_arith_info.exact == 4, .x_stages = the
+    remaining stages); a set that does not admit it runs exact (== 1).  Either way: the oracle within LOGIT_TOL, flat CUs re-run exactly,
+    the same bits through every entry point, and MLT_FLAG_NO_CALIBRATION keeps the exact arithmetic."""
+    import oracle
+    pkg = gpu
+    n = 48
+    seen = set()
+    for size in (64, 32, 16):
+        org, pred = pkg.synth.make_patches_bulk(size, n, 991 + size)
+        poc, qp = pkg.synth.make_scalars(n, 991 + size)
+        org[5] = 300; pred[5] = 300  # constant CU: the flat-content guard re-runs it exactly when layer0 is not exact
+        for seed in (10, 13):
+            blob = pkg.weights.synthetic_blob(1, seed)
+            m = _ctx(pkg, size, blob)
+            a = m.arithmetic(size)
+            print(f"size {size} seed {seed}:", a)
+            assert a["exact"] in (1, 4)
+            seen.add(a["exact"])
+            if a["exact"] == 4:
+                assert a["x_stages"] == 0x1E and a["w2_stages"] in (0, 1) and a["calibrated"] == 1 and a["flat_guard"] == 1
+                assert 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.75e-3
+            ref, ref_split = oracle.Oracle(blob).forward(org, pred, poc, qp, threads=8)
+            s, l = m.predict_batch(org, pred, poc, qp)
+            assert np.abs(l - ref).max() <= LOGIT_TOL
+            assert np.abs(l[5] - ref[5]).max() <= 2e-5
+            sl = head_slices(oracle.Oracle(blob).head_classes)[0]
+            check_splits(s, ref, ref_split, sl, a["exact"] == 1, LOGIT_TOL, f"{size}/{seed}")
+            for i in (0, 5, 11):
+                s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+                assert s1 == s[i] and np.array_equal(l1, l[i]), "single-CU path differs from the batch path"
+            e = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION)
+            assert e.arithmetic(size)["exact"] == 1
+            se, le = e.predict_batch(org, pred, poc, qp)
+            assert np.abs(le - ref).max() <= 2e-5
+            m.close(); e.close()
+    assert 4 in seen, "no small model landed in the calibrated-prefix tier: the test does not cover it"
+
+
 def test_repeated_runs_bit_identical_128(gpu):
     """The conv kernels synchronise by hand (LDS-DMA landing published by counted vmcnt + barrier, fragment reads behind
     counted lgkmcnt): a missing wait shows up as run-to-run differences.  Ragged batch => partial tiles / tail workgroups."""
