@@ -5,7 +5,7 @@
 # 2. rocprofv3 --kernel-trace --stats of the same workload            -> stats/out_kernel_stats.csv
 # 3. HBM traffic: separate --pmc FETCH_SIZE / WRITE_SIZE passes       -> fetch/, write/  (MI355X_MICROARCH.md HBM section)
 # 4. MFMA / LDS / wait counters, one --pmc pass per counter group     -> pmc/<group>/
-# 5. round 4: the other arithmetic tiers (weight seeds 11 / 13 / 23 / 24: hi+lo weights in some stages; 22: exact), the encoder's
+# 5. round 4: the other arithmetic tiers (weight seeds 11 / 13 / 23 / 24: hi+lo weights in some stages; 12 / 21 / 22: exact stages; --flags 1: exact), the encoder's
 #    configuration (decision guard), content mixes (25 % flat-guard content, natural statistics), the small CU sizes, the one-CU timeline
 # Counter passes never combine --pmc with --stats / trace domains other than --kernel-trace.
 set -u
@@ -22,8 +22,8 @@ for grp in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ
   name=$(echo $grp | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc/$name -o out -- python3 scripts/prof_run.py 4096 2 > $out/pmc_$name.log 2>&1
 done
-for s in 11 13 23 24; do python3 bench.py --no-cpu-baseline --weight-seed $s > $out/bench_seed$s.json 2>> $out/bench.err; done
-python3 bench.py --no-cpu-baseline --weight-seed 22 --steps 20 --warmup 5 > $out/bench_seed22.json 2>> $out/bench.err
+for s in 11 13 23 24 12 21 22; do python3 bench.py --no-cpu-baseline --weight-seed $s > $out/bench_seed$s.json 2>> $out/bench.err; done
+python3 bench.py --no-cpu-baseline --flags 1 --steps 20 --warmup 5 > $out/bench_exact.json 2>> $out/bench.err
 python3 bench.py --no-cpu-baseline --flags 4 > $out/bench_decision_guard.json 2>> $out/bench.err
 python3 bench.py --no-cpu-baseline --flat-frac 0.25 --steps 20 --warmup 5 > $out/bench_flat25.json 2>> $out/bench.err
 python3 bench.py --no-cpu-baseline --content natural > $out/bench_natural.json 2>> $out/bench.err
