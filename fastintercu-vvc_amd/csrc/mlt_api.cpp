@@ -53,6 +53,8 @@ struct SizeState {
   bool w2 = false;             // middle tier: the main path runs `model_w2` (hi+lo weights on single fp16 activations, fused kernels); guards as for fast
   unsigned w2_mask = 0;        // ... in the stages whose bit is set (bit s = layer s; all four: the whole network); the other stages stay on the
                                // single-pass kernels of `model` ("mixed" tiers: the calibration picks the CHEAPEST set of stages that meets the contract)
+  unsigned w2_units = 0;       // ... at the granularity the kernels allow: bit 2 s = the first launch unit of layer s (layer0.0 / the stride-2 conv + shortcut),
+                               // bit 2 s + 1 = the second (layer0.1 / the three stride-1 convs); w2_mask = the stages with at least one unit set
   unsigned x_mask = 0;         // round 4, the tier below exact: the stages of this mask run the EXACT arithmetic (model_exact's per-conv kernels, a lo
                                // plane behind their activations), the other stages hi+lo weights (w2_mask = the complement) -- for weight sets whose
                                // ACTIVATION rounding, spread evenly over all 18 rounding sites, misses the contract by a few per cent
@@ -509,8 +511,9 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
 // tier -- `model_w2` (hi+lo WEIGHTS on the fast tiling: the W2 forms of the fused kernels)
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
 // the raw planes as aligned quads, else by flat_stat_kernel)
-// mback != NULL (hi+lo-weights tiers): the stages whose bit is set in back_mask run `mback` (the hi+lo-weights model; same single fp16
-// activation planes, so the two models' stages compose freely), the others `m` (single-pass kernels).
+// mback != NULL (hi+lo-weights tiers): the launch UNITS whose bit is set in back_mask (bit 2 s: layer0.0 / the stride-2 conv + shortcut of
+// layer s; bit 2 s + 1: layer0.1 / the three stride-1 convs of layer s) run `mback` (the hi+lo-weights model; same single fp16 activation
+// planes, so the two models' units compose freely), the others `m` (single-pass kernels).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
                 mlt::Model *mback = nullptr, unsigned back_mask = 0, const GuardTail *tail = nullptr, bool flat_is_clear = false,
@@ -548,10 +551,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   static const bool no_chain_s2 = tuning_env("MLT_NO_CHAIN_S2") != nullptr;
   static const bool no_c16 = tuning_env("MLT_NO_C16") != nullptr;
   static const long chain_min_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
-  auto model_of = [&](int s) -> mlt::Model & { return ((x_mask >> s) & 1u) ? *mx : (mback && ((back_mask >> s) & 1u)) ? *mback : m; };
+  auto model_of = [&](int s, int u) -> mlt::Model & { return ((x_mask >> s) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : m; };
   auto wants_chain = [&](int s, int h_in) -> bool {
     if (s <= 0 || s >= m.n_stages || no_chain) return false;
-    const mlt::Model &mm = model_of(s);
+    const mlt::Model &mm = model_of(s, 1);
     if (mm.exact || (mm.w2 && !ctx->lds_oob_zero)) return false;  // (the hi+lo-weights chains exist in the padding-from-beyond-the-LDS form only)
     const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
     const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
@@ -561,20 +564,25 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const bool packing_ok = (m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3)) && (!mm.w2 || c2.lo8 || m.planes[s] == 64);  // what chain_kernel<C> streams
     return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
-  auto wants_s2 = [&](int s, int h_in) -> bool { return wants_chain(s, h_in) && !no_chain_s2 && model_of(s).blocks[s][0].conv1_s2c.d_w != nullptr; };
+  // (the whole-stage form -- stride-2 conv + shortcut inside the launch -- exists for the single pass only: both units of the stage on `m`)
+  auto wants_s2 = [&](int s, int h_in) -> bool {
+    return wants_chain(s, h_in) && !no_chain_s2 && !model_of(s, 0).w2 && !model_of(s, 1).w2 && model_of(s, 0).blocks[s][0].conv1_s2c.d_w != nullptr;
+  };
   bool cur_c16 = false;  // layout of `cur`
   for (int s = 0; s < m.n_stages; ++s) {
     int hout = h, h2;
     const bool last = s == m.n_stages - 1;
     // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
     // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
-    mlt::Model &ms = model_of(s);  // (hi+lo-weights tiers: the two-plane model for the stages of the mask)
+    mlt::Model &ms = model_of(s, 0);  // (hi+lo-weights tiers: the two-plane model for the units of the mask)
+    mlt::Model &mt = model_of(s, 1);  // second unit: layer0.1, or conv2 of block 0 + block 1 of the later stages
     mlt::Block &B0 = ms.blocks[s][0];
+    mlt::Block &B0c = (s == 0 ? ms : mt).blocks[s][0];  // the model block 0's conv2 comes from
     const int ho = h / 2 > 0 ? h / 2 : 1;
     const bool act_split = ms.exact;
     const size_t lo_in = act_split ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
     const size_t lo_st = act_split ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                      // plane bytes inside the stage
-    if (act_split && s > 0 && !model_of(s - 1).exact) {
+    if (act_split && s > 0 && !model_of(s - 1, 1).exact) {
       // an exact stage behind a single-plane stage: its input has no lo part (the producer wrote fp16 values) -- a plane of zeros
       HIP_TRY(ctx, hipMemsetAsync((char *)const_cast<void *>(cur) + lo_in, 0, lo_in, ctx->stream));
     }
@@ -613,7 +621,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
-        if ((rc = run_chain3(ctx, B0, ms.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
+        if ((rc = run_chain3(ctx, B0c, mt.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
                              cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
         cur = outs[s];
         cur_c16 = out_c16;
@@ -626,12 +634,12 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       io = ConvIO();
       io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
       io.x_lo = io.y_lo = io.res_lo = lo_st;
-      if ((rc = run_conv(ctx, B0.conv2, n, hout, io, &h2))) return rc;
+      if ((rc = run_conv(ctx, B0c.conv2, n, hout, io, &h2))) return rc;
     }
     // block 1 (identity shortcut)
-    mlt::Block &B1 = ms.blocks[s][1];
+    mlt::Block &B1 = mt.blocks[s][1];
     static const bool no_fuse = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
-    if (s == 0 && !ms.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
+    if (s == 0 && !mt.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
       if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
       cur = outs[s];
       h = hout;
@@ -721,7 +729,7 @@ int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_
              bool flat_is_clear = false) {
   // (hi+lo-weights tiers: the two-plane model in the stages of w2_mask, single pass in the others)
   return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat,
-                     st.w2 ? &st.model_w2 : nullptr, st.w2 ? st.w2_mask : 0u, tail, flat_is_clear, st.x_mask ? &st.model_exact : nullptr, st.x_mask);
+                     st.w2 ? &st.model_w2 : nullptr, st.w2 ? st.w2_units : 0u, tail, flat_is_clear, st.x_mask ? &st.model_exact : nullptr, st.x_mask);
 }
 
 // fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
@@ -913,6 +921,18 @@ const CalibInputs &calibration_set(int S) {
 // time: the exact workspace is 5.6 MiB per 128x128 CU), and price(mask) = the set through `model` with hi+lo weights in the stages of
 // `mask` (0: single pass everywhere), leaving in st.calib_rms the WORST pooled rms |dlogit| over {each content class, each head}, in
 // st.calib_max the overall maximum and in tail_ratio max / (rms pooled over everything).
+// stage mask -> launch-unit mask (both units of every stage of the mask)
+static inline unsigned units_of_stages(unsigned stages) {
+  unsigned u = 0;
+  for (int s2 = 0; s2 < 8; ++s2) if ((stages >> s2) & 1u) u |= 3u << (2 * s2);
+  return u;
+}
+static inline unsigned stages_of_units(unsigned units) {
+  unsigned st2 = 0;
+  for (int s2 = 0; s2 < 8; ++s2) if ((units >> (2 * s2)) & 3u) st2 |= 1u << s2;
+  return st2;
+}
+
 struct CalibSession {
   mlt_ctx *ctx; SizeState &st;
   const CalibInputs *in = nullptr;
@@ -992,7 +1012,7 @@ struct CalibSession {
     const double rms_all = std::sqrt(s2_all / ((double)n * nl));
     tail_ratio = (float)(rms_all > 0.0 ? mx / rms_all : 0.0);
     if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
-      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in stages 0x%x, exact in 0x%x): rms per class", st.size, mask, xmask);
+      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in units 0x%x, exact in stages 0x%x): rms per class", st.size, mask, xmask);
       for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
       std::fprintf(stderr, " | per head");
       for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
@@ -1049,7 +1069,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
   st.loaded = false;
   st.exact = st.want_exact && !small_mix;
-  st.w2 = false; st.w2_mask = 0; st.x_mask = 0;
+  st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
@@ -1095,8 +1115,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
             st.model_w2 = std::move(mw);
             if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
           }
-          if ((rc = cal.price(pre, xm))) return fail(rc);
-          if ((ok = within())) { st.x_mask = xm; st.w2_mask = pre; st.w2 = true; }
+          if ((rc = cal.price(units_of_stages(pre), xm))) return fail(rc);
+          if ((ok = within())) { st.x_mask = xm; st.w2_mask = pre; st.w2_units = units_of_stages(pre); st.w2 = true; }
         }
         if (force_k) break;
       }
@@ -1143,8 +1163,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
           for (int k = 0; k < 15 && !w2_ok; ++k) {
             const unsigned mask = force_mask ? (unsigned)std::strtoul(force_mask, nullptr, 0) & 0xFu : order[k];
             if (mask == 0) break;
-            if ((rc = cal.price(mask))) return fail(rc);
-            if ((w2_ok = within() || force_mask != nullptr)) st.w2_mask = mask;   // (a forced mask is kept whatever it measures: knock-out timing builds)
+            if ((rc = cal.price(units_of_stages(mask)))) return fail(rc);
+            if ((w2_ok = within() || force_mask != nullptr)) { st.w2_mask = mask; st.w2_units = units_of_stages(mask); }  // (a forced mask is kept whatever it measures: knock-out timing builds)
             if (force_mask) break;
           }
         }
@@ -1159,8 +1179,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
           for (int k = 0; k < 11 && !w2_ok; ++k) {
             const unsigned xm = force_x ? (unsigned)std::strtoul(force_x, nullptr, 0) & 0xFu : xorder[k];
             if (xm == 0 || xm == 0xFu) break;
-            if ((rc = cal.price(0xFu & ~xm, xm))) return fail(rc);
-            if ((w2_ok = within() || force_x != nullptr)) { st.w2_mask = 0xFu & ~xm; st.x_mask = xm; }
+            if ((rc = cal.price(units_of_stages(0xFu & ~xm), xm))) return fail(rc);
+            if ((w2_ok = within() || force_x != nullptr)) { st.w2_mask = 0xFu & ~xm; st.w2_units = units_of_stages(st.w2_mask); st.x_mask = xm; }
             if (force_x) break;
           }
           if (w2_ok && !force_x) {
@@ -1171,11 +1191,35 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
             for (int k = 0; k < 4; ++k) {
               const unsigned bit = 1u << drop[k];
               if (!(st.w2_mask & bit)) continue;
-              if ((rc = cal.price(st.w2_mask & ~bit, st.x_mask))) return fail(rc);
+              if ((rc = cal.price(units_of_stages(st.w2_mask & ~bit), st.x_mask))) return fail(rc);
               if (within()) { st.w2_mask &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
+            }
+            st.w2_units = units_of_stages(st.w2_mask);
+            st.calib_rms = rms_k; st.calib_max = max_k;
+          }
+        }
+        // ... and at the granularity the kernels allow: each stage is two launch units (layer0.0 | layer0.1; stride-2 conv + shortcut | the
+        // three stride-1 convs), and the units of the two models compose as freely as the stages do.  Drop the hi+lo weights unit by unit, the
+        // largest saving first (measured ms per 4096 CUs of a unit's hi+lo form over what replaces it), keeping a drop only if the contract
+        // still holds.  (A stage whose two units are both back on the single pass runs the whole-stage kernel again.)
+        static const bool no_units = tuning_env("MLT_NO_W2_UNITS") != nullptr;
+        static const char *force_units = tuning_env("MLT_W2_UNITS");
+        if (w2_ok && size == 128 && !no_units && ((!force_mask && !force_x) || force_units)) {
+          if (force_units) {
+            st.w2_units = (unsigned)std::strtoul(force_units, nullptr, 0) & 0xFFu & ~units_of_stages(st.x_mask);
+            if ((rc = cal.price(st.w2_units, st.x_mask))) return fail(rc);
+          } else {
+            static const int drop[8] = {3, 1, 7, 5, 0, 4, 6, 2};  // chain 64 | layer0.1 | chain 256 | chain 128 | layer0.0 | s2 64->128 | s2 128->256 | s2 32->64
+            float rms_k = st.calib_rms, max_k = st.calib_max;
+            for (int k = 0; k < 8; ++k) {
+              const unsigned bit = 1u << drop[k];
+              if (!(st.w2_units & bit)) continue;
+              if ((rc = cal.price(st.w2_units & ~bit, st.x_mask))) return fail(rc);
+              if (within()) { st.w2_units &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
             }
             st.calib_rms = rms_k; st.calib_max = max_k;
           }
+          st.w2_mask = stages_of_units(st.w2_units);
         }
         if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
         else {  // run it exact
@@ -1199,10 +1243,10 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->x_mask ? 4 : st->w2 ? (st->w2_mask != 0xFu ? 3 : 2) : 0;
+  out->exact = st->exact ? 1 : st->x_mask ? 4 : st->w2 ? (st->w2_units != 0xFFu ? 3 : 2) : 0;
   out->w2_stages = st->w2 ? (int32_t)st->w2_mask : 0;
   out->x_stages = st->exact ? 0 : (int32_t)st->x_mask;
-  out->reserved = 0;
+  out->w2_units = st->w2 ? (int32_t)st->w2_units : 0;
   out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;

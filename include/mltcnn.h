@@ -137,7 +137,8 @@ typedef struct mlt_arith_info {
   int32_t w2_stages;      /* ABI 3: bit s set = layer s (0..3) runs (hi, lo) weights; 0 for the fast and the exact arithmetic */
   float guard_margin;     /* ABI 3: the decision guard's threshold in effect for this size (0 when the guard is off) */
   int32_t x_stages;       /* ABI 3: bit s set = layer s runs the exact arithmetic inside a mixed tier (exact == 4); 0 otherwise */
-  int32_t reserved;
+  int32_t w2_units;       /* ABI 3: w2_stages at launch-unit granularity: bit 2 s = layer s's first unit (layer0.0 / its stride-2 conv + shortcut),
+                             bit 2 s + 1 = its second (layer0.1 / its three stride-1 convs) */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 
