@@ -503,7 +503,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
       out->mt = 32 * r.wpb * ((exact && r.cin >= 128 && r.stride == 1) ? CFG_BIG_WP_EXACT : r.wp);
       out->mt_dma = r.dma == 2 ? 32 * r.wpb_dma * r.wp_dma : out->mt;
       // the variants assume weights packed for 128-cout tiles (64 for the 64-channel layer)
-      out->lat = (!exact && r.lat && r.wcb * r.wc == (r.cout == 64 ? 2 : 4)) ? 1 : 0;
+      out->lat = (r.lat && r.wcb * r.wc == (r.cout == 64 ? 2 : 4)) ? 1 : 0;  // (round 4: the exact arithmetic has its latency variants too)
       out->gt = r.gt[exact ? 1 : 0];
       out->gt_w2 = w2_gt(r.cin, r.cout, r.stride, r.gt[1]);
       return true;
@@ -560,6 +560,17 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
     return hipErrorInvalidValue;
   }
 #if CFG_LAT
+  if (variant == MLT_CONV_LATENCY && nsplit == 2) {
+    // Exact arithmetic, small launches (round 4: the guards' re-runs of a few flagged CUs, one-CU calls of the exact / exact-stage tiers, small
+    // batches of the small models): the same 32-cout x 128-pixel tiles on the exact packing (4x the workgroups, a quarter of the weight
+    // bytes each); per accumulator the order of the large tiles (chunk, tap, k-step: Wh Xh, Wh Xl, Wl Xh), so the results are the same bits.
+    if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 32, 2, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 2>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 128 && stride == 1) return launch_conv_t<128, 128, 1, 9, false, 32, 2, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 256 && cout == 256 && stride == 1) return launch_conv_t<256, 256, 1, 9, false, 32, 2, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 2, 1, 1, 1, 4, CFG_GTE_S2, 2, 5, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 2, 1, 1, 1, 4, CFG_GTE_S2, 2, 5, 1, false, 4>(a, grid_x, extra_lds, st);
+    return hipErrorInvalidValue;
+  }
   if (variant == MLT_CONV_LATENCY && !exact) {  // 32 couts x 128 pixels per 4-wave workgroup, weights packed for CBP = 4
     if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 64, 1, 1, 1, 1, 4, 9, 1, 6, 1, false, 2>(a, grid_x, extra_lds, st);
     if (cin == 128 && cout == 128 && stride == 1) return launch_conv_t<128, 128, 1, 9, false, 64, 1, 1, 1, 1, 4, CFG_LAT_GT, 2, 6, 1, false, 4>(a, grid_x, extra_lds, st);

@@ -381,6 +381,8 @@ def test_middle_tier_hi_lo_weights(gpu):
         print(f"seed {seed}:", a)
         assert a["exact"] in ((4,) if seed in (21, 22) else (2, 3)) and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.75e-3 and a["flat_guard"] == 1
         assert (a["x_stages"] != 0) == (a["exact"] == 4) and (a["x_stages"] & a["w2_stages"]) == 0
+        # (launch-unit granularity: a stage counts as hi+lo weights when at least one of its two units is)
+        assert a["w2_stages"] == sum(1 << st for st in range(4) if (a["w2_units"] >> (2 * st)) & 3)
         ref, ref_split = oracle.Oracle(blob).forward(org, pred, poc, qp, threads=8)
         s, l = m.predict_batch(org, pred, poc, qp)
         assert np.abs(l - ref).max() <= LOGIT_TOL
