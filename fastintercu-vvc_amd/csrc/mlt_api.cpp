@@ -1100,7 +1100,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       bool ok = false;
       auto within = [&]() {
         const float kk = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance;
+        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.65f * ctx->tolerance;
       };
       static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
       for (int k = ns - 1; k >= 1 && !ok; --k) {
@@ -1140,7 +1140,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       // weight set) observed.
       auto within = [&]() {
         const float k = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return k * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.75f * ctx->tolerance;
+        return k * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.65f * ctx->tolerance;
       };
       // REFINEMENTS of an admitted configuration (dropping hi+lo weights stage by stage / unit by unit) are held to a stricter rule: a greedy
       // search that keeps every drop that still passes walks the configuration to the edge of the criterion, and with up to a dozen marginal

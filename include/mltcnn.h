@@ -114,7 +114,8 @@ mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
  * constant org / textured pred, textured org / constant pred, a constant band and a near-flat band just under the guard's two thresholds) run
  * through the fast and the exact arithmetic on the device; the fast arithmetic is kept only if
  * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| (over 5040 logits) <=
- * 0.75 x tolerance -- for a set whose largest error exceeds 5 x its overall rms (heavy tail) the 5.5 grows with that ratio, up to 6.5;
+ * 0.65 x tolerance (the largest of 295 k probed logits measured up to 1.7 x the largest of these 5040) -- for a set whose largest
+ * error exceeds 5 x its overall rms (heavy tail) the 5.5 grows with that ratio, up to 6.5;
  * otherwise the 128 model tries the middle tiers the same way -- (hi, lo) pairs for the WEIGHTS only (hi fp16; lo fp16, or e4m3 with a
  * per-layer power-of-two scale where the layer has >= 128 input channels: the lo term carries < 2^-11 of the product), on the W2 forms
  * of the fused kernels, in a SUBSET of the four stages: the 15 subsets are priced in the order of
