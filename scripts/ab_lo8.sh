@@ -1,4 +1,6 @@
-# A/B inside one gpurun call: the hi+lo-weights tiers with the fp16 lo product (lib_base.so = the previous commit) against the FP8 lo product.
+# A/B inside one gpurun call: the hi+lo-weights tiers with the fp16 lo product against the FP8 lo product (profiles/r04m_lo8_ab.txt).
+# lib_base.so = build.build_lib(force=True, out='fastintercu-vvc_amd/_variants/lib_base.so') on a checkout of the commit before the FP8 lo
+# product (797e4c3); the variants directory is not tracked.
 for v in base lo8 base lo8; do
   if [ $v = base ]; then export MLT_LIB_PATH=$PWD/fastintercu-vvc_amd/_variants/lib_base.so; else unset MLT_LIB_PATH; fi
   for s in 13 11; do
