@@ -148,18 +148,19 @@ def test_content_classes_against_oracle(gpu, seed):
         c.close()
 
 
-@pytest.mark.parametrize("seed", [10, 23])
+@pytest.mark.parametrize("seed", [10, 23, 21])
 def test_tails_of_the_shipped_tier_on_a_large_sample(gpu, seed):
-    """The calibration admits an arithmetic on 96 CUs with a Gaussian tail factor; this looks at the tail itself: 2048 texture CUs + 512 of
-    each other calibration class through the tier the calibration picked (seed 10: single pass, seed 23: hi+lo weights in layer2 / layer3)
-    and through the exact arithmetic on the device (itself <= 1e-5 from the oracle, checked elsewhere): no logit beyond the contract, no
-    decisive split flipped.  (scripts/tail_probe.py is the full-size version: 294,912 logits per weight set, worst 7.6e-4.)"""
+    """The calibration admits an arithmetic on 560 CUs with a tail factor; this looks at the tail itself: 2048 texture CUs + 512 of
+    each other calibration class through the tier the calibration picked (seed 10: single pass, seed 23: hi+lo weights in some launch units,
+    seed 21: the exact arithmetic in one stage + hi+lo weights) and through the exact arithmetic on the device (itself <= 1e-5 from the
+    oracle, checked elsewhere): no logit beyond the contract, no decisive split flipped.  (scripts/tail_probe.py is the full-size version:
+    294,912 logits per weight set, worst 8.5e-4 over nine sets: profiles/r04p_tail_probe.txt.)"""
     pkg = gpu
     S, size = pkg.synth, 128
     blob = pkg.weights.synthetic_blob(0, seed)
     m = _ctx(pkg, size, blob)
     e = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
-    assert m.arithmetic(size)["exact"] == (0 if seed == 10 else 3)
+    assert m.arithmetic(size)["exact"] == {10: 0, 23: 3, 21: 4}[seed]
     worst = 0.0
     for kind, n in ((None, 2048), (S.KIND_UNIFORM, 512), (S.KIND_ORG_FLAT_PRED_TEX, 512), (S.KIND_ORG_TEX_PRED_FLAT, 512), (S.KIND_PARTIAL_FLAT, 512)):
         org, pred = S.make_patches_bulk(size, n, 424242) if kind is None else S.make_patches(size, n, 424242 + kind, kind)
