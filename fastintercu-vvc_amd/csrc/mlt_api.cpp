@@ -1090,8 +1090,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
     if (small_mix) {
       // The small models (maps of 1 .. 32 pixels) miss the contract in the single pass -- but their time is in the FIRST stages (the
       // large maps: layer0 + layer1 are 65 % of the 64 x 64 model's exact step) and their error in the LAST ones (nothing for the pooling
-      // to average on 1 .. 16 pixels).  Candidates: the single pass in stages 0 .. k-1, the exact arithmetic from stage k on, longest
-      // prefix (cheapest) first; the admission rule of the 128 model.  No prefix -> exact.
+      // to average on 1 .. 16 pixels).  Candidates: a set of stages in the single pass, the others exact (below); the admission rule of the
+      // 128 model.  No candidate -> exact.
       CalibSession cal(ctx, st);
       if ((rc = cal.begin())) return fail(rc);
       const int ns = st.model.n_stages;
@@ -1103,23 +1103,31 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
         return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.65f * ctx->tolerance;
       };
       static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
-      for (int k = ns - 1; k >= 1 && !ok; --k) {
-        if (force_k) k = std::atoi(force_k) < 1 ? 1 : std::atoi(force_k) > ns - 1 ? ns - 1 : std::atoi(force_k);
-        const unsigned pre = (1u << k) - 1u, xm = all & ~pre;
+      // Candidates: the single pass in stages 0 .. k-1, the exact arithmetic from stage k on, longest prefix (cheapest) first.  (All 30
+      // stage subsets were priced once for the 64 x 64 model, profiles/r04p_small_models_all_subsets.txt: a single-pass stage anywhere but
+      // in front leaves the LAST head -- 2 x 2 maps -- at rms 4.3 .. 7.6e-4, so only prefixes are tried.)  MLT_SMALL_PREFIX=k (tuning)
+      // prices exactly the prefix of k stages.
+      std::vector<std::pair<float, unsigned>> cand;  // (unused cost, mask of the exact stages)
+      for (int k = ns - 1; k >= 1; --k) cand.push_back({0.f, all & ~((1u << k) - 1u)});
+      if (force_k) {
+        const int k = std::atoi(force_k) < 1 ? 1 : std::atoi(force_k) > ns - 1 ? ns - 1 : std::atoi(force_k);
+        cand.assign(1, {0.f, all & ~((1u << k) - 1u)});
+      }
+      for (size_t ci = 0; ci < cand.size() && !ok; ++ci) {
+        const unsigned xm = cand[ci].second;
         if ((rc = cal.price(0, xm))) return fail(rc);
         ok = within() || force_k != nullptr;
         if (ok) st.x_mask = xm;
-        if (!ok && !no_w2 && k == 1) {  // ... layer0 with hi+lo WEIGHTS (the single pass's weight rounding removed; the fused layer0 kernels on 32 x 32 maps)
+        if (!ok && !no_w2 && !(xm & 1u) && (xm | 1u) == all) {  // only layer0 off the exact arithmetic: also with hi+lo WEIGHTS there (the fused layer0 kernels on 32 x 32 maps)
           if (!st.model_w2.on_device) {
             mlt::Model mw;
             if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
             st.model_w2 = std::move(mw);
             if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
           }
-          if ((rc = cal.price(units_of_stages(pre), xm))) return fail(rc);
-          if ((ok = within())) { st.x_mask = xm; st.w2_mask = pre; st.w2_units = units_of_stages(pre); st.w2 = true; }
+          if ((rc = cal.price(units_of_stages(1u), xm))) return fail(rc);
+          if ((ok = within())) { st.x_mask = xm; st.w2_mask = 1u; st.w2_units = units_of_stages(1u); st.w2 = true; }
         }
-        if (force_k) break;
       }
       if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
       if (!ok) {  // run it exact
@@ -1134,7 +1142,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       if ((rc = cal.begin())) return fail(rc);
       if ((rc = cal.price(0))) return fail(rc);
       // Admission: statistical, not a bound.  (i) 5.5 x the worst pooled rms over the content classes / heads of the calibration set (a
-      // Gaussian tail of 4e-8 per logit); (ii) the largest error seen on the 5040 logits, with a 25 % margin; (iii) round 4 -- a set whose
+      // Gaussian tail of 4e-8 per logit); (ii) the largest error seen on the 5040 logits <= 0.65 x tolerance (the tail probes found the largest of 295 k logits at 1.2 .. 1.7 x it); (iii) round 4 -- a set whose
       // largest error exceeds 5 x its overall rms on this sample (a Gaussian sample of this size peaks at 3.8) has a heavy tail: its factor
       // grows with that ratio (1.1 x ratio: continuous at 5) up to 6.5, the worst max / rms ratio the round-3 tail probe (295 k logits per
       // weight set) observed.
