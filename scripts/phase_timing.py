@@ -1,5 +1,5 @@
 """Debug: per-phase cycle breakdown of conv_mfma_kernel (build with -DMLT_PHASE_TIMING).  GPU box only.
-usage: python scripts/phase_timing.py [batch] [exact]"""
+usage: python scripts/phase_timing.py [batch] [exact | seed=<weight seed>]"""
 import ctypes as C
 import os
 import sys
@@ -15,8 +15,9 @@ os.environ["MLT_LIB_PATH"] = out
 import torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-blob = pkg.weights.synthetic_blob(0, 10)
-m = pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob}, max_batch=n, flags=pkg.capi.FLAG_EXACT_128 if 'exact' in sys.argv[2:] else pkg.capi.FLAG_NO_CALIBRATION)
+seed = next((int(a[5:]) for a in sys.argv[2:] if a.startswith('seed=')), 10)
+blob = pkg.weights.synthetic_blob(0, seed)
+m = pkg.MltCnn(device=0, sizes=(128,), blobs={128: blob}, max_batch=n, flags=pkg.capi.FLAG_EXACT_128 if 'exact' in sys.argv[2:] else 0 if seed != 10 else pkg.capi.FLAG_NO_CALIBRATION)
 org, pred = pkg.synth.make_patches_bulk(128, n, 3)
 poc, qp = pkg.synth.make_scalars(n, 3)
 dev = torch.device("cuda:0")
