@@ -58,6 +58,7 @@ struct SizeState {
   unsigned x_mask = 0;         // round 4, the tier below exact: the stages of this mask run the EXACT arithmetic (model_exact's per-conv kernels, a lo
                                // plane behind their activations), the other stages hi+lo weights (w2_mask = the complement) -- for weight sets whose
                                // ACTIVATION rounding, spread evenly over all 18 rounding sites, misses the contract by a few per cent
+  unsigned x_units = 0;        // ... at launch-unit granularity (bit 2 s + u as in w2_units); x_mask = the stages with at least one exact unit
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
   bool small_mix = false;      // 64 / 32 / 16 (round 4): configured exact, but the load-time calibration may keep the first stages -- the large maps, where the
@@ -518,17 +519,17 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
                 mlt::Model *mback = nullptr, unsigned back_mask = 0, const GuardTail *tail = nullptr, bool flat_is_clear = false,
-                mlt::Model *mx = nullptr, unsigned x_mask = 0) {
+                mlt::Model *mx = nullptr, unsigned x_units = 0) {
   const int S = st.size;
-  if (!mx) x_mask = 0;
-  int rc = ensure_ws(ctx, ws_per_cu(m, S, x_mask != 0) * (size_t)n);
+  if (!mx) x_units = 0;
+  int rc = ensure_ws(ctx, ws_per_cu(m, S, x_units != 0) * (size_t)n);
   if (rc) return rc;
   // carve the workspace
   char *p = ctx->ws;
   auto carve = [&](size_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return (void *)r; };
   const int h0 = S / 2 > 0 ? S / 2 : 1;
-  // a lo plane behind every activation (x_mask: room for one behind every buffer, used by the stages of the mask only)
-  const int nplanes = (m.exact || x_mask) ? 2 : 1;
+  // a lo plane behind every activation (x_units: room for one behind every buffer, used by the units of the mask only)
+  const int nplanes = (m.exact || x_units) ? 2 : 1;
   void *pool[4];
   for (int i = 0; i < 4; ++i) pool[i] = carve((size_t)n * h0 * h0 * 32 * 2 * nplanes);
   void *outs[5];
@@ -552,7 +553,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   static const bool no_chain_s2 = tuning_env("MLT_NO_CHAIN_S2") != nullptr;
   static const bool no_c16 = tuning_env("MLT_NO_C16") != nullptr;
   static const long chain_min_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
-  auto model_of = [&](int s, int u) -> mlt::Model & { return ((x_mask >> s) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : m; };
+  auto model_of = [&](int s, int u) -> mlt::Model & { return ((x_units >> (2 * s + u)) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : m; };
   auto wants_chain = [&](int s, int h_in) -> bool {
     if (s <= 0 || s >= m.n_stages || no_chain) return false;
     const mlt::Model &mm = model_of(s, 1);
@@ -580,9 +581,11 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     mlt::Block &B0 = ms.blocks[s][0];
     mlt::Block &B0c = (s == 0 ? ms : mt).blocks[s][0];  // the model block 0's conv2 comes from
     const int ho = h / 2 > 0 ? h / 2 : 1;
-    const bool act_split = ms.exact;
-    const size_t lo_in = act_split ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
-    const size_t lo_st = act_split ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                      // plane bytes inside the stage
+    // (exact units, round 4: a unit in the exact arithmetic keeps a lo plane behind the tensors it writes and expects one behind those it
+    // reads -- a plane of zeros when the producer is a single-plane unit; single-plane units read the hi planes and ignore the offsets)
+    const bool ex0 = ms.exact, ex1 = mt.exact, act_split = ex0;
+    const size_t lo_in = ex0 ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;         // plane bytes of the stage input
+    const size_t lo_st = (ex0 || ex1) ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                    // plane bytes inside the stage
     if (act_split && s > 0 && !model_of(s - 1, 1).exact) {
       // an exact stage behind a single-plane stage: its input has no lo part (the producer wrote fp16 values) -- a plane of zeros
       HIP_TRY(ctx, hipMemsetAsync((char *)const_cast<void *>(cur) + lo_in, 0, lo_in, ctx->stream));
@@ -617,7 +620,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
         // (t -- the chain's input, fetched by LDS-DMA -- stays NHWC: chunk-major, the stride-2 kernel's stores gained what the chain's
         // DMA lost, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)
-        io.ysc_c16 = chain && m.planes[s] == 64 && !no_c16;
+        io.ysc_c16 = chain && m.planes[s] == 64 && !no_c16 && !ex0;  // (the exact kernels write NHWC)
         if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
@@ -631,6 +634,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
         ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
         continue;
+      }
+      if (s > 0 && ex1 && !ex0) {  // t and sc came from a single-plane unit
+        HIP_TRY(ctx, hipMemsetAsync((char *)pool[0] + lo_st, 0, lo_st, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync((char *)pool[1] + lo_st, 0, lo_st, ctx->stream));
       }
       io = ConvIO();
       io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
@@ -646,6 +653,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       h = hout;
       continue;
     }
+    if (s == 0 && ex1 && !ex0) HIP_TRY(ctx, hipMemsetAsync((char *)pool[2] + lo_st, 0, lo_st, ctx->stream));  // b0 came from a single-plane unit
     io = ConvIO();
     io.x = pool[2]; io.y = pool[3]; io.relu = true;
     io.x_lo = io.y_lo = lo_st;
@@ -730,7 +738,7 @@ int run_main(mlt_ctx *ctx, SizeState &st, int n, const int16_t *d_org, long org_
              bool flat_is_clear = false) {
   // (hi+lo-weights tiers: the two-plane model in the stages of w2_mask, single pass in the others)
   return run_network(ctx, st, st.model, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_poc, d_qp, d_split, d_logits, d_flat,
-                     st.w2 ? &st.model_w2 : nullptr, st.w2 ? st.w2_units : 0u, tail, flat_is_clear, st.x_mask ? &st.model_exact : nullptr, st.x_mask);
+                     st.w2 ? &st.model_w2 : nullptr, st.w2 ? st.w2_units : 0u, tail, flat_is_clear, st.x_units ? &st.model_exact : nullptr, st.x_units);
 }
 
 // fast network + guard selection for n CUs, everything asynchronous on ctx->stream; the count lands in g.h_count
@@ -1013,7 +1021,7 @@ struct CalibSession {
     const double rms_all = std::sqrt(s2_all / ((double)n * nl));
     tail_ratio = (float)(rms_all > 0.0 ? mx / rms_all : 0.0);
     if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
-      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in units 0x%x, exact in stages 0x%x): rms per class", st.size, mask, xmask);
+      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in units 0x%x, exact in units 0x%x): rms per class", st.size, mask, xmask);
       for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
       std::fprintf(stderr, " | per head");
       for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
@@ -1070,7 +1078,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
   st.loaded = false;
   st.exact = st.want_exact && !small_mix;
-  st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0;
+  st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
@@ -1115,9 +1123,9 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       }
       for (size_t ci = 0; ci < cand.size() && !ok; ++ci) {
         const unsigned xm = cand[ci].second;
-        if ((rc = cal.price(0, xm))) return fail(rc);
+        if ((rc = cal.price(0, units_of_stages(xm)))) return fail(rc);
         ok = within() || force_k != nullptr;
-        if (ok) st.x_mask = xm;
+        if (ok) { st.x_mask = xm; st.x_units = units_of_stages(xm); }
         if (!ok && !no_w2 && !(xm & 1u) && (xm | 1u) == all) {  // only layer0 off the exact arithmetic: also with hi+lo WEIGHTS there (the fused layer0 kernels on 32 x 32 maps)
           if (!st.model_w2.on_device) {
             mlt::Model mw;
@@ -1125,8 +1133,18 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
             st.model_w2 = std::move(mw);
             if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
           }
-          if ((rc = cal.price(units_of_stages(1u), xm))) return fail(rc);
-          if ((ok = within())) { st.x_mask = xm; st.w2_mask = 1u; st.w2_units = units_of_stages(1u); st.w2 = true; }
+          if ((rc = cal.price(units_of_stages(1u), units_of_stages(xm)))) return fail(rc);
+          if ((ok = within())) { st.x_mask = xm; st.x_units = units_of_stages(xm); st.w2_mask = 1u; st.w2_units = units_of_stages(1u); st.w2 = true; }
+        }
+      }
+      if (!ok && !force_k) {
+        // ... and HALF of layer0 off the exact arithmetic (launch units: layer0.0 = stem + conv1 + conv2 + shortcut | layer0.1 = the identity
+        // block): what keeps the 64 x 64 model exact is the activation rounding of layer0's four rounding sites together
+        const unsigned rest = units_of_stages(all & ~1u);
+        static const unsigned half[2] = {0x2u, 0x1u};  // exact units of layer0: layer0.1 only (layer0.0 single pass) | layer0.0 only
+        for (int hh = 0; hh < 2 && !ok; ++hh) {
+          if ((rc = cal.price(0, rest | half[hh]))) return fail(rc);
+          if ((ok = within())) { st.x_units = rest | half[hh]; st.x_mask = all; }
         }
       }
       if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
@@ -1198,8 +1216,8 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
           for (int k = 0; k < 11 && !w2_ok; ++k) {
             const unsigned xm = force_x ? (unsigned)std::strtoul(force_x, nullptr, 0) & 0xFu : xorder[k];
             if (xm == 0 || xm == 0xFu) break;
-            if ((rc = cal.price(units_of_stages(0xFu & ~xm), xm))) return fail(rc);
-            if ((w2_ok = within() || force_x != nullptr)) { st.w2_mask = 0xFu & ~xm; st.w2_units = units_of_stages(st.w2_mask); st.x_mask = xm; }
+            if ((rc = cal.price(units_of_stages(0xFu & ~xm), units_of_stages(xm)))) return fail(rc);
+            if ((w2_ok = within() || force_x != nullptr)) { st.w2_mask = 0xFu & ~xm; st.w2_units = units_of_stages(st.w2_mask); st.x_mask = xm; st.x_units = units_of_stages(xm); }
             if (force_x) break;
           }
           if (w2_ok && !force_x) {
@@ -1210,7 +1228,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
             for (int k = 0; k < 4; ++k) {
               const unsigned bit = 1u << drop[k];
               if (!(st.w2_mask & bit)) continue;
-              if ((rc = cal.price(units_of_stages(st.w2_mask & ~bit), st.x_mask))) return fail(rc);
+              if ((rc = cal.price(units_of_stages(st.w2_mask & ~bit), st.x_units))) return fail(rc);
               if (within_refined()) { st.w2_mask &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
             }
             st.w2_units = units_of_stages(st.w2_mask);
@@ -1225,19 +1243,35 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
         static const char *force_units = tuning_env("MLT_W2_UNITS");
         if (w2_ok && size == 128 && !no_units && ((!force_mask && !force_x) || force_units)) {
           if (force_units) {
-            st.w2_units = (unsigned)std::strtoul(force_units, nullptr, 0) & 0xFFu & ~units_of_stages(st.x_mask);
-            if ((rc = cal.price(st.w2_units, st.x_mask))) return fail(rc);
+            st.w2_units = (unsigned)std::strtoul(force_units, nullptr, 0) & 0xFFu & ~st.x_units;
+            if ((rc = cal.price(st.w2_units, st.x_units))) return fail(rc);
           } else {
             static const int drop[8] = {3, 1, 7, 5, 0, 4, 6, 2};  // chain 64 | layer0.1 | chain 256 | chain 128 | layer0.0 | s2 64->128 | s2 128->256 | s2 32->64
             float rms_k = st.calib_rms, max_k = st.calib_max;
             for (int k = 0; k < 8; ++k) {
               const unsigned bit = 1u << drop[k];
               if (!(st.w2_units & bit)) continue;
-              if ((rc = cal.price(st.w2_units & ~bit, st.x_mask))) return fail(rc);
+              if ((rc = cal.price(st.w2_units & ~bit, st.x_units))) return fail(rc);
               if (within_refined()) { st.w2_units &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
             }
             st.calib_rms = rms_k; st.calib_max = max_k;
           }
+          st.w2_mask = stages_of_units(st.w2_units);
+        }
+        // ... and the exact stages of the tier below exact, unit by unit: an exact unit goes back to its hi+lo-weights form (the stride-1
+        // chains first: 2.6 ms exact against 1.3 - 1.6 with hi+lo weights; then the stride-2 convs), under the refinement rule
+        static const bool no_xunits = tuning_env("MLT_NO_X_UNITS") != nullptr;
+        if (w2_ok && size == 128 && st.x_units && !no_xunits && !force_x && !force_mask && !force_units) {
+          static const int xdrop[8] = {3, 5, 7, 1, 2, 4, 6, 0};
+          float rms_k = st.calib_rms, max_k = st.calib_max;
+          for (int k = 0; k < 8; ++k) {
+            const unsigned bit = 1u << xdrop[k];
+            if (!(st.x_units & bit)) continue;
+            if ((rc = cal.price(st.w2_units | bit, st.x_units & ~bit))) return fail(rc);
+            if (within_refined()) { st.x_units &= ~bit; st.w2_units |= bit; rms_k = st.calib_rms; max_k = st.calib_max; }
+          }
+          st.calib_rms = rms_k; st.calib_max = max_k;
+          st.x_mask = stages_of_units(st.x_units);
           st.w2_mask = stages_of_units(st.w2_units);
         }
         if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
@@ -1262,10 +1296,12 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->x_mask ? 4 : st->w2 ? (st->w2_units != 0xFFu ? 3 : 2) : 0;
+  out->exact = st->exact ? 1 : st->x_units ? 4 : st->w2 ? (st->w2_units != 0xFFu ? 3 : 2) : 0;
   out->w2_stages = st->w2 ? (int32_t)st->w2_mask : 0;
   out->x_stages = st->exact ? 0 : (int32_t)st->x_mask;
   out->w2_units = st->w2 ? (int32_t)st->w2_units : 0;
+  out->x_units = st->exact ? 0 : (int32_t)st->x_units;
+  out->reserved = 0;
   out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;

@@ -140,6 +140,8 @@ typedef struct mlt_arith_info {
   int32_t x_stages;       /* ABI 3: bit s set = layer s runs the exact arithmetic inside a mixed tier (exact == 4); 0 otherwise */
   int32_t w2_units;       /* ABI 3: w2_stages at launch-unit granularity: bit 2 s = layer s's first unit (layer0.0 / its stride-2 conv + shortcut),
                              bit 2 s + 1 = its second (layer0.1 / its three stride-1 convs) */
+  int32_t x_units;        /* ABI 3: x_stages at the same launch-unit granularity */
+  int32_t reserved;
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 

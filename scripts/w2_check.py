@@ -27,7 +27,7 @@ for seed in seeds:
     s1, l1 = m.predict_batch(org[:k], pred[:k], poc[:k], qp[:k])
     sp, lp = m.predict(org[2], pred[2], int(poc[2]), int(qp[2]))
     ref, rs = oracle.Oracle(blob).forward(org[:24], pred[:24], poc[:24], qp[:24], threads=8)
-    print(f"seed {seed}: tier {a['exact']} w2 0x{a['w2_stages']:x} (units 0x{a['w2_units']:x}) x 0x{a['x_stages']:x} calib rms {a['calib_rms']:.2e} max {a['calib_max']:.2e} | deterministic {np.array_equal(l, l2)} | "
+    print(f"seed {seed}: tier {a['exact']} w2 0x{a['w2_stages']:x} (units 0x{a['w2_units']:x}) x 0x{a['x_stages']:x} (units 0x{a['x_units']:x}) calib rms {a['calib_rms']:.2e} max {a['calib_max']:.2e} | deterministic {np.array_equal(l, l2)} | "
           f"large == small {np.array_equal(l[:k], l1)} (max diff {np.abs(l[:k] - l1).max():.2e}) | predict == batch {np.array_equal(lp, l[2])} | "
           f"vs oracle: large {np.abs(l[:24] - ref).max():.2e} small {np.abs(l1 - ref[:k]).max():.2e} | finite {np.isfinite(l).all()}")
     m.close()

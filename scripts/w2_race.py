@@ -20,7 +20,7 @@ for seed in seeds:
     blob = pkg.weights.synthetic_blob(0, seed)
     m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, max_batch=4096)
     a = m.arithmetic(size)
-    print(f"seed {seed}: tier {a['exact']} units 0x{a['w2_units']:x} exact stages 0x{a['x_stages']:x}", flush=True)
+    print(f"seed {seed}: tier {a['exact']} units 0x{a['w2_units']:x} exact units 0x{a['x_units']:x}", flush=True)
     for n in (4096, 1001, 257, 37, 1):
         org, pred = pkg.synth.make_patches_bulk(size, n, 99 + n)
         poc, qp = pkg.synth.make_scalars(n, 99 + n)
