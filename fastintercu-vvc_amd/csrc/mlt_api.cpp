@@ -583,16 +583,15 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const int ho = h / 2 > 0 ? h / 2 : 1;
     // (exact units, round 4: a unit in the exact arithmetic keeps a lo plane behind the tensors it writes and expects one behind those it
     // reads -- a plane of zeros when the producer is a single-plane unit; single-plane units read the hi planes and ignore the offsets)
-    const bool ex0 = ms.exact, ex1 = mt.exact, act_split = ex0;
+    const bool ex0 = ms.exact, ex1 = mt.exact;
     const size_t lo_in = ex0 ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;         // plane bytes of the stage input
     const size_t lo_st = (ex0 || ex1) ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                    // plane bytes inside the stage
-    if (act_split && s > 0 && !model_of(s - 1, 1).exact) {
-      // an exact stage behind a single-plane stage: its input has no lo part (the producer wrote fp16 values) -- a plane of zeros
-      HIP_TRY(ctx, hipMemsetAsync((char *)const_cast<void *>(cur) + lo_in, 0, lo_in, ctx->stream));
-    }
+    // an exact unit behind a single-plane unit: its input has no lo part (the producer wrote fp16 values): lo offset 0 = "no lo plane, read
+    // zeros" (ConvArgs.x_lo_off / res_lo_off)
+    const bool in_has_lo = s > 0 && model_of(s - 1, 1).exact;
     ConvIO io;
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
-    io.x_lo = lo_in; io.y_lo = lo_st; io.ysc_lo = lo_st;
+    io.x_lo = in_has_lo ? lo_in : 0; io.y_lo = lo_st; io.ysc_lo = lo_st;
     static const bool no_fuse0 = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
     // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
     const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
@@ -635,13 +634,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
         continue;
       }
-      if (s > 0 && ex1 && !ex0) {  // t and sc came from a single-plane unit
-        HIP_TRY(ctx, hipMemsetAsync((char *)pool[0] + lo_st, 0, lo_st, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync((char *)pool[1] + lo_st, 0, lo_st, ctx->stream));
-      }
       io = ConvIO();
       io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
       io.x_lo = io.y_lo = io.res_lo = lo_st;
+      if (s > 0 && ex1 && !ex0) io.x_lo = io.res_lo = 0;  // t and sc came from a single-plane unit
       if ((rc = run_conv(ctx, B0c.conv2, n, hout, io, &h2))) return rc;
     }
     // block 1 (identity shortcut)
@@ -653,14 +649,16 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       h = hout;
       continue;
     }
-    if (s == 0 && ex1 && !ex0) HIP_TRY(ctx, hipMemsetAsync((char *)pool[2] + lo_st, 0, lo_st, ctx->stream));  // b0 came from a single-plane unit
+    const bool b0_has_lo = s == 0 ? ex0 : ex1;  // (b0 = pool[2] is written by unit 0 of layer0, by unit 1 of the later stages)
     io = ConvIO();
     io.x = pool[2]; io.y = pool[3]; io.relu = true;
     io.x_lo = io.y_lo = lo_st;
+    if (!b0_has_lo) io.x_lo = 0;
     if ((rc = run_conv(ctx, B1.conv1, n, hout, io, &h2))) return rc;
     io = ConvIO();
     io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
     io.x_lo = io.y_lo = io.res_lo = lo_st;
+    if (!b0_has_lo) io.res_lo = 0;
     io.y_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
     if ((rc = run_conv(ctx, B1.conv2, n, hout, io, &h2))) return rc;
     cur = outs[s];

@@ -47,7 +47,7 @@ struct ConvArgs {
   float *gap;
   int gap_slots, gap_l;
   // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
-  size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;
+  size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;  // exact arithmetic: byte offsets hi plane -> lo plane (x_lo_off / res_lo_off == 0: that input has no lo plane, its lo part is zero)
   int lo8_scale;               // NSPLIT == 5 (hi fp16 + FP8 lo plane): E8M0 scale byte of the lo plane, replicated (mlt_model.h: lo8_exp)
 };
 
