@@ -1104,9 +1104,11 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
       const unsigned all = (1u << ns) - 1u;
       static const char *force_k = tuning_env("MLT_SMALL_PREFIX");
       bool ok = false;
+      // (the largest error is held to 0.5 x tolerance here, not 0.65: the small models' tails are heavier -- few pixels to average -- and
+      // their 491 k-logit tail probes measured 1.5 .. 1.85 x the calibration set's largest error, profiles/r04s_tail_probe_{64,32}.txt)
       auto within = [&]() {
         const float kk = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.65f * ctx->tolerance;
+        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.5f * ctx->tolerance;
       };
       static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
       // Candidates: the single pass in stages 0 .. k-1, the exact arithmetic from stage k on, longest prefix (cheapest) first.  (All 30

@@ -19,9 +19,11 @@ def main():
     ap.add_argument("--seeds", default="10,23,13")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--n-texture", type=int, default=16384)
+    ap.add_argument("--size", type=int, default=128, help="CU size (round 4: the small models' calibrated tiers too)")
     a = ap.parse_args()
     pkg = mltcnn_pkg.load()
-    S, size = pkg.synth, 128
+    S, size = pkg.synth, a.size
+    arch = S.arch_for_size(size)
     classes = [("texture", None), ("uniform", S.KIND_UNIFORM), ("org_flat_pred_tex", S.KIND_ORG_FLAT_PRED_TEX),
                ("org_tex_pred_flat", S.KIND_ORG_TEX_PRED_FLAT), ("partial_flat", S.KIND_PARTIAL_FLAT)]
     data = {}
@@ -31,13 +33,14 @@ def main():
         poc, qp = S.make_scalars(n, 31337 + (kind or 0))
         data[name] = (org, pred, poc, qp)
         print(f"generated {name}: {n} CUs", flush=True)
-    heads = [slice(0, 2), slice(2, 5), slice(5, 9)]
+    heads = [slice(0, 2), slice(2, 5), slice(5, 9)] if size == 128 else [slice(0, 2), slice(2, 5), slice(5, 9), slice(9, 15)]
+    dec = 2 if size == 128 else 0  # decision head (EncCu.cpp:913-919)
     for seed in [int(v) for v in a.seeds.split(",")]:
-        blob = pkg.weights.synthetic_blob(0, seed)
+        blob = pkg.weights.synthetic_blob(arch, seed)
         m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob})
-        e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128)
+        e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128 if size == 128 else pkg.capi.FLAG_NO_CALIBRATION)
         ar = m.arithmetic(size)
-        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 hi+lo weights in stages 0x{ar['w2_stages']:x}, 2 hi+lo weights everywhere, 4 exact in stages 0x{ar['x_stages']:x} + hi+lo weights in 0x{ar['w2_stages']:x}, 1 exact), calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
+        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 hi+lo weights in stages 0x{ar['w2_stages']:x}, 2 hi+lo weights everywhere, 4 exact in stages 0x{ar['x_stages']:x} + hi+lo weights in 0x{ar['w2_stages']:x}, 1 exact), exact units 0x{ar['x_units']:x}, hi+lo units 0x{ar['w2_units']:x}; calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
         tot_n = tot_bad = 0
         worst = 0.0
         for name, _ in classes:
@@ -49,7 +52,7 @@ def main():
             rms = np.sqrt((d * d).mean())
             per_head = [np.sqrt((d[:, h] ** 2).mean()) for h in heads]
             bad = int((d > 1e-3).sum())
-            srt = np.sort(l2[:, heads[2]].astype(np.float64), axis=1)
+            srt = np.sort(l2[:, heads[dec]].astype(np.float64), axis=1)
             decisive = (srt[:, -1] - srt[:, -2]) > 2e-3
             flips = int(((s1 != s2) & decisive).sum())
             tot_n += d.size; tot_bad += bad; worst = max(worst, float(d.max()))
