@@ -17,8 +17,9 @@ dev = torch.device("cuda", 0)
 bad = 0
 # (128: calibration off so that the fast kernels -- whole-stage kernels for large launches, per-conv variants for small ones -- are
 # the ones screened; 257 / 1001: odd sample counts = a half-empty last tile of the two-samples-per-workgroup 256-channel stage)
-for size, flags, batches in ((128, pkg.capi.FLAG_NO_CALIBRATION, (4096, 1001, 257, 65, 37, 1)), (64, pkg.capi.FLAG_FAST_SMALL, (4096, 333)), (32, 0, (2048,))):
-    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 5)
+for size, flags, batches in ((128, pkg.capi.FLAG_NO_CALIBRATION, (4096, 1001, 257, 65, 37, 1)), (64, pkg.capi.FLAG_FAST_SMALL, (4096, 333)), (32, 0, (2048,)),
+                             (64, 0, (4096, 333, 1)), (16, 0, (4096, 77))):   # round 4: the calibrated tiers of the small models (seed 10: 64 keeps layer0.0, 16 all of layer0 single-pass)
+    blob = pkg.weights.synthetic_blob(pkg.synth.arch_for_size(size), 10 if flags == 0 and size in (64, 16) else 5)
     m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, max_batch=max(batches), flags=flags)
     nl = m.num_logits(size)
     for B in batches:
