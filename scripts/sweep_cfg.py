@@ -14,9 +14,10 @@ VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); ru
     # round 4: taps per weight step of the exact arithmetic's per-conv kernels (SWEEP_ARGS="--weight-seed 22" = the exact 128 model, "--size 64")
     # (gte_s2_2 / gte_s2_5 / gte_s1_3: profiles/r04h_sweep_exact*.txt -- CFG_GTE_S2 = 2 became the default)
     # patch items per lane prefetched in registers, exact arithmetic (phase stamps: the synchronous tail of the commit is 36 - 45 % of the 32-channel launches)
-    "une_5": ["CFG_UNE_32=5", "CFG_UNE_S2=5"],
-    "une_5_all": ["CFG_UNE_32=5", "CFG_UNE_S2=5", "CFG_UNE_64=5"],
-    "une_6": ["CFG_UNE_32=6", "CFG_UNE_S2=6"],
+    # (une_5 / une_5_all / une_6: profiles/r04m_sweep_exact_prefetch.txt -- CFG_UNE_32 = 5 became the default)
+    # 32 -> 32 per-conv kernels on 256-pixel tiles (4 waves): the exact form then fits two workgroups per CU (78 KiB of LDS each instead of 122)
+    "x32_wp4": ["CFG_32_WP=4"],
+    "x32_wp4_une3": ["CFG_32_WP=4", "CFG_UNE_32=3"],
 }
 # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
 #   "s2_wp8": ["CFG_3264_WP=8"], "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"]
