@@ -388,7 +388,7 @@ def main():
                    "parallelism": f"shard{world}",
                    "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
-                                  "w2_stages": int(arith["w2_stages"]), "w2_units": int(arith["w2_units"]), "x_stages": int(arith["x_stages"]), "x_units": int(arith["x_units"]), "decision_guard_margin": arith["guard_margin"],
+                                  "w2_stages": int(arith["w2_stages"]), "w2_units": int(arith["w2_units"]), "x_stages": int(arith["x_stages"]), "x_units": int(arith["x_units"]), "weight_rounding": int(arith["rounding"]), "decision_guard_margin": arith["guard_margin"],
                                   "guard_reruns_total": arith["guard_reruns"], "guard_reruns_per_step": round(reruns_per_step, 2),
                                   "guard_rerun_fraction": round(reruns_per_step / B, 5)},
                    "content": args.content if args.flat_frac == 0 else f"{args.content} + {args.flat_frac:g} flat / dither / ramp / low-contrast CUs"},

@@ -37,7 +37,7 @@ class MltConfig(C.Structure):
 class MltArithInfo(C.Structure):
     _fields_ = [("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
                 ("flat_guard", C.c_int32), ("decision_guard", C.c_int32), ("guard_reruns", C.c_uint64),
-                ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("reserved", C.c_int32)]
+                ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("rounding", C.c_int32)]
 
 
 class MltKernelTime(C.Structure):

@@ -1179,6 +1179,32 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
         return k * st.calib_rms <= 0.95f * ctx->tolerance && st.calib_max <= 0.6f * ctx->tolerance;
       };
       static const char *force_mask = tuning_env("MLT_W2_MASK");  // tuning: price exactly this stage mask (even when the single pass would do)
+      // The single pass failed with the weights' default rounding: the same arithmetic with another REALISATION of the tap-diffused rounding
+      // (mlt_model.h: tap order of the diffusion, error carried across input channels or not -- every weight still within one ulp).  The
+      // realisations are draws of one error distribution (CPU emulation, scripts/emul_fast.py: the worst head's rms moves by +-25 % between
+      // them for one weight set, none is better on average), so a set a little over the line may have one under it -- and then runs the
+      // single pass at full speed instead of hi+lo weights in two or three stages.  Same admission rule; at most 5 more packings
+      // (~50 ms each), only for sets that fail.
+      static const bool no_roundings = tuning_env("MLT_NO_ROUNDINGS") != nullptr;
+      static const char *force_rounding = tuning_env("MLT_ROUNDING");
+      if ((!within() || force_rounding) && size == 128 && !no_roundings && !force_mask) {
+        const float rms0 = st.calib_rms, max0 = st.calib_max;
+        bool got = false;
+        for (int v = 1; v < mlt::MLT_N_ROUNDINGS && !got; ++v) {
+          if (force_rounding) v = std::atoi(force_rounding) < 0 ? 0 : std::atoi(force_rounding) >= mlt::MLT_N_ROUNDINGS ? mlt::MLT_N_ROUNDINGS - 1 : std::atoi(force_rounding);
+          mlt::Model mv;
+          if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_FAST, size, mv, err, v)) { ctx->err = "weights (rounding " + std::to_string(v) + "): " + err; return fail(MLT_ERR_WEIGHTS); }
+          if ((rc = upload_model(ctx, mv))) { free_model(mv); return fail(rc); }
+          std::swap(st.model, mv);              // price() runs st.model
+          rc = cal.price(0);
+          got = rc == MLT_OK && (within() || force_rounding != nullptr);
+          if (!got) std::swap(st.model, mv);    // back to the default rounding
+          free_model(mv);
+          if (rc) return fail(rc);
+          if (force_rounding) break;
+        }
+        if (!got) { st.calib_rms = rms0; st.calib_max = max0; (void)cal.price(0); }  // (calib figures and tail ratio of the default rounding again)
+      }
       if (!within() || force_mask) {
         // Single-pass fp16 does not meet the contract for this weight set.  Middle tiers: hi+lo WEIGHTS on single fp16 activations (2 MFMAs
         // per product on the W2 forms of the fused kernels -- a third copy of the weights, on the fast tiling; the weight rounding is what
@@ -1301,7 +1327,7 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   out->x_stages = st->exact ? 0 : (int32_t)st->x_mask;
   out->w2_units = st->w2 ? (int32_t)st->w2_units : 0;
   out->x_units = st->exact ? 0 : (int32_t)st->x_units;
-  out->reserved = 0;
+  out->rounding = st->model.rounding;
   out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;

@@ -127,7 +127,7 @@ static void fold_scale(const BlobView &b, const std::string &prefix, int c, std:
 // w: torch layout [cout][cin][taps]; scale: per-cout multiplier; w_sc (optional): [cout][cin] 1x1 shortcut.
 // Output: fragment-packed fp16 (see header).
 static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> &scale, const float *w_sc,
-                      const std::vector<double> &scale_sc) {
+                      const std::vector<double> &scale_sc, int rounding = 0) {
   const int cin = pc.cin, cout = pc.cout, taps = pc.taps, tt = taps + (w_sc ? 1 : 0);
   const int KC = pc.kc, NCHUNK = cin / KC, KS = KC / 16, CT = pc.ct, CBT = CT / 32;
   pc.plane_halves = (size_t)cout * cin * tt;
@@ -167,19 +167,28 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
     hi_slot = q;
     lo8v[flat] = exact - (double)f16_to_f32(q);
   };
+  // rounding realisations of the single-pass model (mlt_model.h): tap order of the error diffusion, and whether the error carries across cin
+  static const int kOrder[MLT_N_ROUNDINGS][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8}, {8, 7, 6, 5, 4, 3, 2, 1, 0},
+                                                 {0, 3, 6, 7, 4, 1, 2, 5, 8}, {4, 5, 2, 1, 0, 3, 6, 7, 8}, {0, 1, 2, 5, 4, 3, 6, 7, 8}};
+  static const bool kCarry[MLT_N_ROUNDINGS] = {false, true, false, false, false, true};
+  const int rv = (!two && taps == 9 && rounding > 0 && rounding < MLT_N_ROUNDINGS) ? rounding : 0;
   for (int co = 0; co < cout; ++co) {
     const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
+    double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of one (co, ci) -- or of one co (carried roundings)
     for (int ci = 0; ci < cin; ++ci) {
       const int chunk = ci / KC, kk = ci % KC, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
       auto at = [&](int t) -> uint16_t & {
         return pc.w[((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j];
       };
-      double err = 0.0;  // running (sum of rounded) - (sum of exact) over the taps of this (co, ci)
+      if (!kCarry[rv]) err = 0.0;
       if (pc.lo8) {
         for (int t = 0; t < taps; ++t) put8(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], ((size_t)co * cin + ci) * tt + t);
         continue;
       }
-      for (int t = 0; t < taps; ++t) put(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], err);
+      for (int k = 0; k < taps; ++k) {
+        const int t = taps == 9 ? kOrder[rv][k] : k;
+        put(at(t), (double)w[((size_t)co * cin + ci) * taps + t] * scale[co], err);
+      }
       double err_sc = 0.0;
       if (w_sc) put(at(taps), (double)w_sc[(size_t)co * cin + ci] * scale_sc[co], err_sc);
     }
@@ -329,7 +338,7 @@ static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const 
     }
 }
 
-bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err) {
+bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err, int rounding) {
   const bool exact = mode == MLT_MODEL_EXACT, w2 = mode == MLT_MODEL_W2;
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
@@ -348,6 +357,7 @@ bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, s
   m.arch = (int)h->arch;
   m.exact = exact;
   m.w2 = w2;
+  m.rounding = (exact || w2) ? 0 : rounding;
   static const int planes_ctu[4] = {32, 64, 128, 256}, planes_cu[5] = {32, 64, 96, 128, 256};  // arch:243-256 / cu arch:63-79
   static const int cls_ctu[3] = {2, 3, 4}, cls_cu[4] = {2, 3, 4, 6};
   m.n_stages = m.arch == 0 ? 4 : 5;
@@ -418,7 +428,7 @@ bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, s
           fold_scale(b, nm, c, scale_sc, pc.bias_sc, err);
           if (!err.empty()) return false;
         }
-        pack_conv(pc, w, scale, wsc, scale_sc);
+        pack_conv(pc, w, scale, wsc, scale_sc, m.rounding);
         return true;
       };
       const bool has_sc = (st != 1 || bin != c);  // arch:44-45
@@ -441,7 +451,7 @@ bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, s
         std::snprintf(nm, sizeof nm, "layer%d.%d.shortcut.1", s, bi);
         fold_scale(b, nm, c, scale_sc, pc.bias_sc, err);
         if (!err.empty()) return false;
-        pack_conv(pc, w, scale, wsc, scale_sc);
+        pack_conv(pc, w, scale, wsc, scale_sc, m.rounding);
       }
       if (!make(B.conv2, "conv2.weight", "bn2", c, 1, false)) return false;
     }

@@ -59,10 +59,17 @@ struct Model {
   Block blocks[5][2];
   Head heads[4];
   bool on_device = false;
+  int rounding = 0;         // MLT_MODEL_FAST: the rounding realisation of the 3x3 layers (build_model)
 };
 
 enum { MLT_MODEL_FAST = 0, MLT_MODEL_EXACT = 1, MLT_MODEL_W2 = 2 };  // tap-diffused single fp16 plane / (hi, lo) planes on the exact tiling / (hi, lo) planes on the fast tiling
-bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err);  // size: CU size the model will serve
+// rounding (MLT_MODEL_FAST only, round 4): which realisation of the tap-diffused rounding the 3x3 layers get -- 0: raster tap order, error
+// reset per (cout, cin) pair (rounds 1-3); 1: raster, error carried across cin; 2: reversed taps; 3: column-major taps; 4: spiral from the
+// centre; 5: serpentine, carried across cin.  Every one keeps each weight within one ulp and cancels the rounding error along spatially
+// adjacent taps; they differ by which weights take which error, i.e. they are different draws of the same error distribution, and the
+// load-time calibration may pick the draw that suits a weight set (mlt_api.cpp).
+enum { MLT_N_ROUNDINGS = 6 };
+bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err, int rounding = 0);  // size: CU size the model will serve
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
 

@@ -116,6 +116,7 @@ mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
  * 5.5 x (the worst rms|dlogit| pooled per content class and per head) <= tolerance and max|dlogit| (over 5040 logits) <=
  * 0.65 x tolerance (the largest of 295 k probed logits measured up to 1.7 x the largest of these 5040) -- for a set whose largest
  * error exceeds 5 x its overall rms (heavy tail) the 5.5 grows with that ratio, up to 6.5;
+ * first with the default realisation of the weights' tap-diffused rounding, then with five others (mlt_arith_info.rounding);
  * otherwise the 128 model tries the middle tiers the same way -- (hi, lo) pairs for the WEIGHTS only (hi fp16; lo fp16, or e4m3 with a
  * per-layer power-of-two scale where the layer has >= 128 input channels: the lo term carries < 2^-11 of the product), on the W2 forms
  * of the fused kernels, in a SUBSET of the four stages: the 15 subsets are priced in the order of
@@ -141,7 +142,7 @@ typedef struct mlt_arith_info {
   int32_t w2_units;       /* ABI 3: w2_stages at launch-unit granularity: bit 2 s = layer s's first unit (layer0.0 / its stride-2 conv + shortcut),
                              bit 2 s + 1 = its second (layer0.1 / its three stride-1 convs) */
   int32_t x_units;        /* ABI 3: x_stages at the same launch-unit granularity */
-  int32_t reserved;
+  int32_t rounding;       /* ABI 3: which realisation of the single-pass weights' tap-diffused rounding the calibration kept (0 = the default) */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 

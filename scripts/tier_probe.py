@@ -25,6 +25,6 @@ for seed in seeds:
     a = m.arithmetic(size)
     s, l = m.predict_batch(org, pred, poc, qp)
     ref, rs = oracle.Oracle(blob).forward(org, pred, poc, qp, threads=8)
-    print(f"seed {seed}: tier {a['exact']} stages 0x{a['w2_stages']:x} (units 0x{a['w2_units']:x}) exact-stages 0x{a['x_stages']:x} (units 0x{a['x_units']:x}) calib rms {a['calib_rms']:.2e} max {a['calib_max']:.2e} load {dt:.2f} s "
+    print(f"seed {seed}: tier {a['exact']} rounding {a['rounding']} stages 0x{a['w2_stages']:x} (units 0x{a['w2_units']:x}) exact-stages 0x{a['x_stages']:x} (units 0x{a['x_units']:x}) calib rms {a['calib_rms']:.2e} max {a['calib_max']:.2e} load {dt:.2f} s "
           f"| vs oracle {np.abs(l - ref).max():.2e}", flush=True)
     m.close()

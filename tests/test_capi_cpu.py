@@ -35,7 +35,7 @@ def test_config_struct_layout(pkg):
     assert pkg.capi.MltConfig.n_devices.offset == 56 and pkg.capi.MltConfig.devices.offset == 60
     assert pkg.capi.MltConfig.guard_margin.offset == 44
     assert pkg.capi.MltConfig.tolerance.offset == 48
-    assert C.sizeof(pkg.capi.MltArithInfo) == 56   # ABI 3: + w2_stages, guard_margin, x_stages, w2_units, x_units, reserved
+    assert C.sizeof(pkg.capi.MltArithInfo) == 56   # ABI 3: + w2_stages, guard_margin, x_stages, w2_units, x_units, rounding
     assert pkg.capi.MltArithInfo.w2_stages.offset == 32 and pkg.capi.MltArithInfo.guard_margin.offset == 36
     assert pkg.capi.MltConfig.weights_dir.offset == 8
     assert pkg.capi.MltConfig.head_index.offset == 20

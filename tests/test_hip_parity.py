@@ -148,11 +148,12 @@ def test_content_classes_against_oracle(gpu, seed):
         c.close()
 
 
-@pytest.mark.parametrize("seed", [10, 23, 21])
+@pytest.mark.parametrize("seed", [10, 23, 11, 21])
 def test_tails_of_the_shipped_tier_on_a_large_sample(gpu, seed):
     """The calibration admits an arithmetic on 560 CUs with a tail factor; this looks at the tail itself: 2048 texture CUs + 512 of
-    each other calibration class through the tier the calibration picked (seed 10: single pass, seed 23: hi+lo weights in some launch units,
-    seed 21: the exact arithmetic in one stage + hi+lo weights) and through the exact arithmetic on the device (itself <= 1e-5 from the
+    each other calibration class through the tier the calibration picked (seed 10: single pass; seed 23: single pass with another realisation of
+    the weights' tap-diffused rounding -- the default one misses the contract; seed 11: hi+lo weights in some launch units; seed 21: the exact
+    arithmetic in one stage + hi+lo weights) and through the exact arithmetic on the device (itself <= 1e-5 from the
     oracle, checked elsewhere): no logit beyond the contract, no decisive split flipped.  (scripts/tail_probe.py is the full-size version:
     294,912 logits per weight set, worst 8.5e-4 over nine sets: profiles/r04p_tail_probe.txt.)"""
     pkg = gpu
@@ -160,7 +161,8 @@ def test_tails_of_the_shipped_tier_on_a_large_sample(gpu, seed):
     blob = pkg.weights.synthetic_blob(0, seed)
     m = _ctx(pkg, size, blob)
     e = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
-    assert m.arithmetic(size)["exact"] == {10: 0, 23: 3, 21: 4}[seed]
+    assert m.arithmetic(size)["exact"] == {10: 0, 23: 0, 11: 3, 21: 4}[seed]
+    assert (m.arithmetic(size)["rounding"] != 0) == (seed == 23)
     worst = 0.0
     for kind, n in ((None, 2048), (S.KIND_UNIFORM, 512), (S.KIND_ORG_FLAT_PRED_TEX, 512), (S.KIND_ORG_TEX_PRED_FLAT, 512), (S.KIND_PARTIAL_FLAT, 512)):
         org, pred = S.make_patches_bulk(size, n, 424242) if kind is None else S.make_patches(size, n, 424242 + kind, kind)
@@ -375,7 +377,7 @@ def test_middle_tier_hi_lo_weights(gpu):
     org, pred = pkg.synth.make_patches_bulk(size, n, 4711)
     poc, qp = pkg.synth.make_scalars(n, 4711)
     org[3] = 512; pred[3] = 512  # a constant CU: flagged by the flat-content guard, re-evaluated exactly
-    for seed in (13, 24, 23, 21, 22):   # 23: admitted with hi+lo weights in two stages only (exact == 3); 21, 22: exact stages (exact == 4)
+    for seed in (13, 24, 11, 21, 22):   # 11: admitted with hi+lo weights in two stages only (exact == 3); 21, 22: exact stages (exact == 4)
         blob = pkg.weights.synthetic_blob(0, seed)
         m = _ctx(pkg, size, blob)
         a = m.arithmetic(size)
