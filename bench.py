@@ -46,7 +46,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (C oracle over the whole batch = full-batch parity, torch port)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CUs of the batch the C oracle evaluates (default: whole batch when the host has >= 64 cores)")
     ap.add_argument("--weight-seed", type=int, default=10, help="seed of the synthetic weight set (10 = the BASELINE workload; 13 / 24 land in the hi+lo-weights tier)")
-    ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags (1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16, 4 = decision guard: the encoder's configuration)")
+    ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags; 0 = the shipped configuration (calibrated arithmetic + flat-content guard + decision guard, what the encoder runs); "
+                         "1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16, 0x20 = without the decision guard (measurement only)")
+    ap.add_argument("--sustain-s", type=float, default=8.0,
+                    help="seconds of back-to-back steps AFTER the timed region for derived.sustained_cu_per_s (the 50-step region lasts 0.25 s on a cool chip; "
+                         "the part is power-limited) and of fp16 GEMMs for derived.mfma_sustained (the box's own MFMA ceiling); 0 = skip both")
     ap.add_argument("--flat-frac", type=float, default=0.0,
                     help="fraction of the batch replaced by content the flat-content guard re-evaluates exactly (constant / dither / ramp / low contrast in turn); 0 = the BASELINE workload")
     ap.add_argument("--content", choices=("texture", "natural"), default="texture",
@@ -209,6 +213,37 @@ def main():
         elapsed = float(te.item())
         rates = [B * args.steps / float(x.item()) for x in allt]
         per_rank = {"cu_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1)}
+    # ---- sustained figures (outside the timed region, every rank: the power envelope is per package) ----
+    # (i) the same step back to back for --sustain-s seconds; (ii) the MFMA rate THIS box sustains over the same time on a plain fp16 GEMM
+    # (hipBLASLt through torch.matmul, 8192^3, operands with post-ReLU-like statistics: |N(0,1)| activations, N(0, 1/K) weights): the part
+    # runs into its power limit long before the 2.5 PFLOP/s nominal peak, and roofline.frac_of_sustained is quoted against this ceiling
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / max(elapsed / max(args.steps, 1), 1e-4)))
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        sus_s = time.perf_counter() - c0
+        gm = 8192
+        ga = torch.randn((gm, gm), device=dev, dtype=torch.float32).abs_().to(torch.float16)
+        gb = (torch.randn((gm, gm), device=dev, dtype=torch.float32) / gm ** 0.5).to(torch.float16)
+        gc = torch.empty((gm, gm), device=dev, dtype=torch.float16)
+        for _ in range(5):
+            torch.matmul(ga, gb, out=gc)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        n_gemm = 0
+        while time.perf_counter() - c0 < args.sustain_s:
+            for _ in range(50):
+                torch.matmul(ga, gb, out=gc)
+            torch.cuda.synchronize()
+            n_gemm += 50
+        gemm_s = time.perf_counter() - c0
+        sustained = {"cu_per_s": B * n_sus / sus_s, "steps": n_sus, "seconds": sus_s,
+                     "mfma_tflops": 2.0 * gm ** 3 * n_gemm / gemm_s / 1e12, "gemm_seconds": gemm_s, "gemm": f"{gm}^3 fp16 torch.matmul (hipBLASLt), fp32 accumulate"}
+        del ga, gb, gc
     # ---- the same steps again with HIP events around every kernel launch (on the launch stream): per-kernel table ----
     m.profile_enable(True)
     for _ in range(args.steps):
@@ -254,8 +289,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    # ---- per-kernel table; roofline of the dominant kernel = the one with the largest ALGORITHMIC FLOP share of a step
-    # (a function of the layer shapes only; ties -> name order), so the choice cannot flip on timing noise ----
+    # ---- per-kernel table; roofline of the dominant kernel = the LONGEST launch of a step (largest average launch duration) ----
     kernels = []
     tot_ms = sum(r["total_ms"] for r in prof) or 1.0
     tot_flops = sum(r["flops"] for r in prof) or 1.0
@@ -287,7 +321,7 @@ def main():
         k["traffic"] = t["hbm_bytes_per_launch"] if t else None
         k["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / by, 3) if t and by > 0 else None
     roofline = None
-    dom = min(prof, key=lambda r: (-r["flops"], r["name"])) if prof else None
+    dom = max(prof, key=lambda r: (r["total_ms"] / max(r["launches"], 1), r["name"])) if prof else None
     if dom:
         avg_ms = dom["total_ms"] / dom["launches"]
         flops_l, bytes_l = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
@@ -303,7 +337,9 @@ def main():
         if mfma_bound:
             ach = flops_l / (avg_ms * 1e-3) / 1e12
             roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_sustained": round(ach / sustained["mfma_tflops"], 4) if sustained else None,
+                        "sustained_peak": round(sustained["mfma_tflops"], 1) if sustained else None}
         else:
             ach = bytes_l / (avg_ms * 1e-3) / 1e9
             roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -311,7 +347,7 @@ def main():
         roofline.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                          "algo_flops_per_launch": flops_l, "algo_bytes_per_launch": bytes_l,
                          "flop_per_byte": round(flops_l / max(bytes_l, 1.0), 1),
-                         "selection": "largest algorithmic FLOP share of a step (ties: name order)"})
+                         "selection": "longest launch of a step (largest average launch duration over the profiled steps)"})
 
     # ---- CPU legs (rank 0, N = 1 only): the C oracle over the batch = parity of EVERY CU of the timed workload and the
     # second baseline row; the torch-CPU port timed per SURVEY.md §8(d) = cpu_baseline.value ----
@@ -403,6 +439,11 @@ def main():
                     "whole_path": {"t_bound_ms": round(t_bound_ms, 4), "t_measured_ms": round(ms_per_step, 4),
                                    "frac": round(t_bound_ms / max(ms_per_step, 1e-9), 4),
                                    "note": "sum over launches of max(algorithmic FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) / measured step time"},
+                    "sustained_cu_per_s": round(world * sustained["cu_per_s"], 1) if sustained else None,
+                    "sustained": None if not sustained else {"steps": sustained["steps"], "seconds": round(sustained["seconds"], 2), "per_gpu_cu_per_s": round(sustained["cu_per_s"], 1),
+                                                             "hbm_layerwise_roofline_frac": round(sustained["cu_per_s"] * LAYERWISE_BYTES_PER_CU[size] / 1e9 / HBM_PEAK_GBS, 4)},
+                    "mfma_sustained": None if not sustained else {"tflops": round(sustained["mfma_tflops"], 1), "seconds": round(sustained["gemm_seconds"], 2), "gemm": sustained["gemm"],
+                                                                  "whole_net_frac_of_sustained": round(value / world * FLOP_PER_CU[size] / 1e12 / sustained["mfma_tflops"], 4)},
                     "batch1_sync_call_us": None if batch1_us is None else round(batch1_us, 1),
                     "host_staged_cu_per_s": None if staged is None else round(staged, 1),
                     "source_sig": source_signature(),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmltcnn_hip.so")
 SOURCES = ["mlt_kernels.hip", "mlt_model.cpp", "mlt_api.cpp"]
-HEADERS = ["mlt_kernels.h", "mlt_model.h", "mlt_conv_kernels.inc", "mlt_chain_kernel.inc", "mlt_front_kernels.inc", "mlt_tail_kernels.inc",
+HEADERS = ["mlt_kernels.h", "mlt_model.h", "mlt_tier_search.h", "mlt_conv_kernels.inc", "mlt_chain_kernel.inc", "mlt_front_kernels.inc", "mlt_tail_kernels.inc",
            os.path.join("..", "..", "include", "mltcnn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]

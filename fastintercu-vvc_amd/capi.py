@@ -19,10 +19,11 @@ ERR_NAMES = {1: "MLT_ERR_ARG", 2: "MLT_ERR_NO_DEVICE", 3: "MLT_ERR_WEIGHTS", 4: 
 SIZE_BITS = {128: 1, 64: 2, 32: 4, 16: 8}
 FLAG_EXACT_128 = 0x1   # 128x128 in exact (fp16 hi+lo, 3-pass) arithmetic instead of fast
 FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
-FLAG_DECISION_GUARD = 0x4  # CUs with a near-tie on the decision head are re-evaluated with the exact arithmetic
+FLAG_DECISION_GUARD = 0x4  # ABI <= 3 opt-in; since ABI 4 the decision guard is the default (accepted, no effect)
 FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (measurement only)
 FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
-EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
+FLAG_NO_DECISION_GUARD = 0x20  # ABI 4: no exact re-evaluation of CUs with a near-tie on the decision head (measurement only)
+EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_calibrate", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
 
@@ -35,9 +36,10 @@ class MltConfig(C.Structure):
 
 
 class MltArithInfo(C.Structure):
-    _fields_ = [("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
+    _fields_ = [("struct_size", C.c_uint32), ("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
                 ("flat_guard", C.c_int32), ("decision_guard", C.c_int32), ("guard_reruns", C.c_uint64),
-                ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("rounding", C.c_int32)]
+                ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("rounding", C.c_int32),
+                ("calib_cus", C.c_int32), ("calib_caller_cus", C.c_int32)]
 
 
 class MltKernelTime(C.Structure):
@@ -79,6 +81,7 @@ def load_library():
     lib.mlt_device_ctx.restype = vp
     lib.mlt_load_weights.argtypes = [vp, i32, vp, C.c_size_t]
     lib.mlt_arithmetic.argtypes = [vp, i32, C.POINTER(MltArithInfo)]
+    lib.mlt_calibrate.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32]
     lib.mlt_predict.argtypes = [vp, vp, i32, vp, i32, i32, C.c_int32, C.c_int32, vp, vp]
     lib.mlt_predict_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mlt_predict_batch_device.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -151,24 +154,36 @@ class MltCnn:
         buf = C.create_string_buffer(blob, len(blob))
         self._check(self._lib.mlt_load_weights(self._h, size, buf, len(blob)))
 
+    def calibrate(self, size: int, org: np.ndarray, pred: np.ndarray, poc, qp, replace: bool = False):
+        """Repeat the load-time calibration of `size` with the caller's CUs appended to (or replacing) the synthetic set (mlt_calibrate)."""
+        org = np.ascontiguousarray(org, np.int16)
+        pred = np.ascontiguousarray(pred, np.int16)
+        poc = np.ascontiguousarray(poc, np.int32)
+        qp = np.ascontiguousarray(qp, np.int32)
+        n = org.shape[0]
+        assert org.shape == (n, size, size) and pred.shape == org.shape and poc.shape == (n,) and qp.shape == (n,)
+        self._check(self._lib.mlt_calibrate(self._h, size, org.ctypes.data, pred.ctypes.data, poc.ctypes.data, qp.ctypes.data, n, 1 if replace else 0))
+
     def arithmetic(self, size: int) -> dict:
         """Arithmetic the size runs after loading (fast / exact), what the calibration measured, guard activity."""
         info = MltArithInfo()
+        info.struct_size = C.sizeof(MltArithInfo)
         self._check(self._lib.mlt_arithmetic(self._h, size, C.byref(info)))
-        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_}
+        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_ if k != "struct_size"}
 
     def num_devices(self) -> int:
         return self._lib.mlt_num_devices(self._h)
 
     def arithmetic_of_device(self, index: int, size: int) -> dict:
         info = MltArithInfo()
+        info.struct_size = C.sizeof(MltArithInfo)
         h = self._lib.mlt_device_ctx(self._h, index)
         if not h:
             raise MltError(1, "no such device index")
         rc = self._lib.mlt_arithmetic(h, size, C.byref(info))
         if rc != MLT_OK:
             raise MltError(rc, self._lib.mlt_last_error(h).decode())
-        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_}
+        return {k: getattr(info, k) for k, _ in MltArithInfo._fields_ if k != "struct_size"}
 
     def num_logits(self, size: int) -> int:
         return self._lib.mlt_num_logits(size)

@@ -22,6 +22,7 @@
 #include "../../include/mltcnn.h"
 #include "mlt_kernels.h"
 #include "mlt_model.h"
+#include "mlt_tier_search.h"
 
 namespace {
 
@@ -65,6 +66,8 @@ struct SizeState {
                                // time is -- on the single-pass kernels (x_mask = the remaining stages); exact when no prefix meets the contract
   bool calibrated = false;
   float calib_rms = 0.f, calib_max = 0.f;
+  int calib_cus = 0, calib_caller_cus = 0;   // CUs the last calibration priced (after dropping those the flat guard re-evaluates anyway) / of them the caller's (mlt_calibrate)
+  std::vector<char> blob;      // host copy of the MLTW blob the size was loaded from (mlt_calibrate re-packs from it)
   uint64_t reruns = 0;         // CUs re-evaluated by the guards
   // run_checked's sleep: measured duration (enqueue -> flagged-CU count on the host) of a guarded chunk, per power-of-two bucket of the chunk
   // size (a 4-CU tail costs ~50 us per CU, a 4096-CU chunk ~1.2: ONE per-CU figure for all sizes made a tail's measurement inflate the
@@ -129,7 +132,7 @@ struct mlt_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   SizeState sz[4];
-  float guard_margin = 2e-3f;  // decision guard: 2 x tolerance unless configured (mlt_init)
+  float guard_margin = 3e-3f;  // decision guard: 3 x tolerance unless configured (mlt_init)
   int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
@@ -866,9 +869,10 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
 // (content the guard catches -- constant, dithered, low-contrast, ramps -- is evaluated with the exact arithmetic anyway).
 // Round 4: 560 CUs (160 + 5 x 80; round 3: 96) = 5040 logits of the 128 model, so that the LARGEST error seen is a statistic with some power:
 // a Gaussian sample of that size peaks at 3.9 sigma, the round-3 tail probe found weight sets whose worst error sits at 6.5 x their rms.
-constexpr int kCalibClasses = 6;
+constexpr int kCalibClasses = 6;          // synthetic content classes; class kCalibClasses = the caller's own CUs (mlt_calibrate)
 constexpr int kCalibCount[kCalibClasses] = {160, 80, 80, 80, 80, 80};
 constexpr int kCalibN = 560;
+constexpr int kCalibCallerMax = 4096;     // caller-supplied CUs per mlt_calibrate call (64 KiB of planes each at S = 128)
 
 struct CalibInputs { std::vector<int16_t> org, pred; std::vector<int32_t> poc, qp; std::vector<int> cls; };
 
@@ -924,25 +928,21 @@ const CalibInputs &calibration_set(int S) {
   return ci;
 }
 
-// One calibration session of mlt_load_weights: the calibration set resident on the device, its exact logits (computed ONCE, 96 CUs at a
-// time: the exact workspace is 5.6 MiB per 128x128 CU), and price(mask) = the set through `model` with hi+lo weights in the stages of
-// `mask` (0: single pass everywhere), leaving in st.calib_rms the WORST pooled rms |dlogit| over {each content class, each head}, in
-// st.calib_max the overall maximum and in tail_ratio max / (rms pooled over everything).
-// stage mask -> launch-unit mask (both units of every stage of the mask)
-static inline unsigned units_of_stages(unsigned stages) {
-  unsigned u = 0;
-  for (int s2 = 0; s2 < 8; ++s2) if ((stages >> s2) & 1u) u |= 3u << (2 * s2);
-  return u;
-}
-static inline unsigned stages_of_units(unsigned units) {
-  unsigned st2 = 0;
-  for (int s2 = 0; s2 < 8; ++s2) if ((units >> (2 * s2)) & 3u) st2 |= 1u << s2;
-  return st2;
-}
+// The caller's own content for the calibration (mlt_calibrate): n dense CUs in HOST memory, appended to the synthetic set or replacing it.
+struct CalibExtra { const int16_t *org, *pred; const int32_t *poc, *qp; int n; bool replace; };
 
+// One calibration session: the calibration CUs resident on the device (the synthetic set, the caller's CUs, or both), their exact logits
+// (computed ONCE, 96 CUs at a time: the exact workspace is 5.6 MiB per 128x128 CU), and price(w2 units, exact units) = the set through
+// `model` with hi+lo weights / the exact arithmetic in those launch units (0: single pass everywhere), leaving in st.calib_rms the WORST
+// pooled rms |dlogit| over {each content class, each head}, in st.calib_max the overall maximum and in tail_ratio max / (rms pooled over
+// everything).  Caller CUs the flat-content guard would re-evaluate exactly anyway (same statistic, same thresholds) do not count: the
+// admission is about what the non-exact arithmetic will really see.
 struct CalibSession {
   mlt_ctx *ctx; SizeState &st;
-  const CalibInputs *in = nullptr;
+  const CalibExtra *extra;
+  int n = 0, n_syn = 0, n_used = 0, n_caller_used = 0;
+  std::vector<int> cls;
+  std::vector<char> use;
   char *d = nullptr;
   int16_t *d_org = nullptr, *d_pred = nullptr;
   int32_t *d_poc = nullptr, *d_qp = nullptr, *d_split = nullptr;
@@ -950,7 +950,7 @@ struct CalibSession {
   std::vector<float> le, lf;
   float tail_ratio = 0.f;
   static constexpr int kSub = 96;
-  CalibSession(mlt_ctx *c, SizeState &s) : ctx(c), st(s) {}
+  CalibSession(mlt_ctx *c, SizeState &s, const CalibExtra *e = nullptr) : ctx(c), st(s), extra(e) {}
   ~CalibSession() {
     if (d) (void)hipFree(d);
     // the workspace grew to 96 exact CUs (540 MiB at S = 128): release it, the first real call sizes it for its own batch (a max_batch = 1
@@ -965,62 +965,94 @@ struct CalibSession {
     const bool prof = ctx->profile;
     ctx->profile = false;
     int rc = MLT_OK;
-    for (int i0 = 0; i0 < kCalibN && rc == MLT_OK; i0 += kSub) {
-      const int c = kCalibN - i0 < kSub ? kCalibN - i0 : kSub;
+    for (int i0 = 0; i0 < n && rc == MLT_OK; i0 += kSub) {
+      const int c = n - i0 < kSub ? n - i0 : kSub;
       rc = exact ? run_network(ctx, st, st.model_exact, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl)
                  : run_network(ctx, st, st.model, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl,
                                nullptr, mask ? &st.model_w2 : nullptr, mask, nullptr, false, xmask ? &st.model_exact : nullptr, xmask);
     }
     ctx->profile = prof;
     if (rc) return rc;
-    out.resize((size_t)kCalibN * nl);
+    out.resize((size_t)n * nl);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out.data(), d_lg, out.size() * 4, hipMemcpyDeviceToHost));
     return MLT_OK;
   }
   int begin() {
     const int S = st.size, nl = st.model.n_logits;
-    const size_t cs = (size_t)S * S, plane = cs * 2 * kCalibN;
-    in = &calibration_set(S);
-    HIP_TRY(ctx, hipMalloc((void **)&d, 2 * plane + 3 * (size_t)kCalibN * 4 + (size_t)kCalibN * nl * 4));
+    const size_t cs = (size_t)S * S;
+    const CalibInputs *syn = (extra && extra->replace) ? nullptr : &calibration_set(S);
+    n_syn = syn ? kCalibN : 0;
+    const int n_ex = extra ? extra->n : 0;
+    n = n_syn + n_ex;
+    const size_t plane = cs * 2 * (size_t)n;
+    cls.assign((size_t)n, kCalibClasses);
+    use.assign((size_t)n, 1);
+    if (syn) std::copy(syn->cls.begin(), syn->cls.end(), cls.begin());
+    HIP_TRY(ctx, hipMalloc((void **)&d, 2 * plane + 3 * (size_t)n * 4 + (size_t)n * nl * 4));
     d_org = (int16_t *)d; d_pred = (int16_t *)(d + plane);
-    d_poc = (int32_t *)(d + 2 * plane); d_qp = d_poc + kCalibN; d_split = d_qp + kCalibN;
-    d_lg = (float *)(d_split + kCalibN);
-    HIP_TRY(ctx, hipMemcpy(d_org, in->org.data(), plane, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(d_pred, in->pred.data(), plane, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(d_poc, in->poc.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(d_qp, in->qp.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
+    d_poc = (int32_t *)(d + 2 * plane); d_qp = d_poc + n; d_split = d_qp + n;
+    d_lg = (float *)(d_split + n);
+    if (syn) {
+      HIP_TRY(ctx, hipMemcpy(d_org, syn->org.data(), cs * 2 * kCalibN, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_pred, syn->pred.data(), cs * 2 * kCalibN, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_poc, syn->poc.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_qp, syn->qp.data(), (size_t)kCalibN * 4, hipMemcpyHostToDevice));
+    }
+    if (n_ex) {
+      HIP_TRY(ctx, hipMemcpy(d_org + cs * n_syn, extra->org, cs * 2 * (size_t)n_ex, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_pred + cs * n_syn, extra->pred, cs * 2 * (size_t)n_ex, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_poc + n_syn, extra->poc, (size_t)n_ex * 4, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, hipMemcpy(d_qp + n_syn, extra->qp, (size_t)n_ex * 4, hipMemcpyHostToDevice));
+      if (st.flat_guard) {
+        // which of the caller's CUs the flat-content guard re-evaluates exactly at run time (flat_stat_kernel's statistic, guard_select_kernel's
+        // thresholds): those never see the arithmetic being priced
+        FlatStatArgs fa{};
+        fa.org = d_org + cs * n_syn; fa.pred = d_pred + cs * n_syn; fa.org_row_stride = S; fa.org_cu_stride = (long)cs; fa.pred_row_stride = S;
+        fa.pred_cu_stride = (long)cs; fa.flat = d_split; fa.n = n_ex; fa.s_l = ilog2(S);
+        HIP_TRY(ctx, mlt_launch_flat_stat(fa, true, ctx->stream));
+        std::vector<int32_t> fl((size_t)n_ex);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(fl.data(), d_split, (size_t)n_ex * 4, hipMemcpyDeviceToHost));
+        const int flat_thr = (S * S / 4) / 8, near_thr = (S * S / 4) / 2;
+        for (int i = 0; i < n_ex; ++i)
+          if ((fl[(size_t)i] >> MLT_FLAT_EXACT_SHIFT) >= flat_thr || (fl[(size_t)i] & 0xFFFF) >= near_thr) use[(size_t)(n_syn + i)] = 0;
+      }
+    }
+    n_used = 0; n_caller_used = 0;
+    for (int i = 0; i < n; ++i) { n_used += use[(size_t)i]; if (i >= n_syn) n_caller_used += use[(size_t)i]; }
     return run(le, true, 0);
   }
   int price(unsigned mask, unsigned xmask = 0) {
     int rc = run(lf, false, mask, xmask);
     if (rc) return rc;
-    const int n = kCalibN, nl = st.model.n_logits;
+    const int nl = st.model.n_logits;
     double mx = 0.0, s2_all = 0.0;
-    double s2_cls[kCalibClasses] = {0}, s2_head[4] = {0};
-    size_t n_cls[kCalibClasses] = {0}, n_head[4] = {0};
+    double s2_cls[kCalibClasses + 1] = {0}, s2_head[4] = {0};
+    size_t n_cls[kCalibClasses + 1] = {0}, n_head[4] = {0}, n_all = 0;
     for (int i = 0; i < n; ++i) {
+      if (!use[(size_t)i]) continue;
       int lo = 0;
       for (int h = 0; h < st.model.n_heads; ++h) {
         for (int k = 0; k < st.model.heads[h].classes; ++k) {
           const size_t j = (size_t)i * nl + lo + k;
           const double e = std::fabs((double)lf[j] - (double)le[j]);
           if (!(e <= mx)) mx = e;  // NaN -> mx = NaN -> fails the admission test
-          s2_cls[in->cls[i]] += e * e; ++n_cls[in->cls[i]];
+          s2_cls[cls[(size_t)i]] += e * e; ++n_cls[cls[(size_t)i]];
           s2_head[h] += e * e; ++n_head[h];
-          s2_all += e * e;
+          s2_all += e * e; ++n_all;
         }
         lo += st.model.heads[h].classes;
       }
     }
     double worst = 0.0;
-    for (int c = 0; c < kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
+    for (int c = 0; c <= kCalibClasses; ++c) if (n_cls[c]) { const double r = std::sqrt(s2_cls[c] / (double)n_cls[c]); if (!(r <= worst)) worst = r; }
     for (int h = 0; h < st.model.n_heads; ++h) if (n_head[h]) { const double r = std::sqrt(s2_head[h] / (double)n_head[h]); if (!(r <= worst)) worst = r; }
-    const double rms_all = std::sqrt(s2_all / ((double)n * nl));
+    const double rms_all = n_all ? std::sqrt(s2_all / (double)n_all) : 0.0;
     tail_ratio = (float)(rms_all > 0.0 ? mx / rms_all : 0.0);
     if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
-      std::fprintf(stderr, "mltcnn calibration (size %d, hi+lo weights in units 0x%x, exact in units 0x%x): rms per class", st.size, mask, xmask);
-      for (int c = 0; c < kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
+      std::fprintf(stderr, "mltcnn calibration (size %d, %d CUs of which %d the caller's, hi+lo weights in units 0x%x, exact in units 0x%x): rms per class", st.size, n_used, n_caller_used, mask, xmask);
+      for (int c = 0; c <= kCalibClasses; ++c) std::fprintf(stderr, " %.3e", std::sqrt(s2_cls[c] / (double)(n_cls[c] ? n_cls[c] : 1)));
       std::fprintf(stderr, " | per head");
       for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", std::sqrt(s2_head[h] / (double)(n_head[h] ? n_head[h] : 1)));
       std::fprintf(stderr, " | max %.3e = %.1f x rms\n", mx, (double)tail_ratio);
@@ -1039,23 +1071,54 @@ void drop_graphs(mlt_ctx *ctx, int si) {  // a captured kernel chain bakes in we
   sg.exec = nullptr; sg.graph = nullptr;
 }
 
-}  // namespace
-
-extern "C" {
-#pragma GCC visibility push(default)
-
-int mlt_abi_version(void) { return MLT_ABI_VERSION; }
-
-int mlt_num_logits(int size) { return size == 128 ? 9 : (size == 64 || size == 32 || size == 16) ? 15 : 0; }
-
-const char *mlt_last_error(const mlt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
-
-int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
-  if (!ctx || !blob) return MLT_ERR_ARG;
-  for (mlt_ctx *p : ctx->peers) {  // one host blob, uploaded (and calibrated) once per device
-    const int rc = mlt_load_weights(p, size, blob, bytes);
-    if (rc) { ctx->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
+// The pricer of the tier search (mlt_tier_search.h) on the device: a configuration = launch units in hi+lo weights / in the exact arithmetic +
+// the realisation of the single-pass weights' rounding.  Models are built and uploaded lazily: another realisation replaces st.model
+// (~50 ms each), the hi+lo-weights copy appears with the first candidate that needs it.
+struct DevicePricer : mlt::TierPricer {
+  mlt_ctx *ctx; SizeState &st; CalibSession &cal;
+  const void *blob; size_t bytes; int size;
+  int cur_rounding = 0;
+  DevicePricer(mlt_ctx *c, SizeState &s, CalibSession &cs, const void *b, size_t n, int sz) : ctx(c), st(s), cal(cs), blob(b), bytes(n), size(sz) {}
+  int price(unsigned w2_units, unsigned x_units, int rounding, mlt::TierPrice &out) override {
+    std::string err;
+    int rc;
+    if (rounding != cur_rounding) {
+      mlt::Model mv;
+      if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_FAST, size, mv, err, rounding)) { ctx->err = "weights (rounding " + std::to_string(rounding) + "): " + err; return MLT_ERR_WEIGHTS; }
+      if ((rc = upload_model(ctx, mv))) { free_model(mv); return rc; }
+      std::swap(st.model, mv);
+      free_model(mv);
+      cur_rounding = rounding;
+    }
+    if (w2_units && !st.model_w2.on_device) {
+      mlt::Model mw;
+      if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return MLT_ERR_WEIGHTS; }
+      st.model_w2 = std::move(mw);
+      if ((rc = upload_model(ctx, st.model_w2))) return rc;
+    }
+    if ((rc = cal.price(w2_units, x_units))) return rc;
+    out.rms = st.calib_rms; out.max = st.calib_max; out.tail = cal.tail_ratio;
+    return MLT_OK;
   }
+};
+
+int env_int(const char *name) {  // tuning switch holding a number (MLT_TUNING=1 only); -1: not set
+  const char *e = tuning_env(name);
+  return e ? (int)std::strtol(e, nullptr, 0) : -1;
+}
+
+void unload_size(mlt_ctx *ctx, int si) {
+  SizeState &st = ctx->sz[si];
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx, si);
+  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
+  st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model();
+  st.loaded = false;
+}
+
+// Load (or re-calibrate: `extra` = the caller's CUs) ONE device's copy of a size.  blob / bytes stay valid for the call.
+int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const CalibExtra *extra) {
   const int si = size_index(size);
   if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
   SizeState &st = ctx->sz[si];
@@ -1078,6 +1141,7 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   st.exact = st.want_exact && !small_mix;
   st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
+  st.calib_cus = st.calib_caller_cus = 0;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
   st.model_w2 = mlt::Model();
@@ -1093,246 +1157,41 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
     if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_EXACT, size, me, err)) { ctx->err = "weights (exact copy): " + err; return fail(MLT_ERR_WEIGHTS); }
     st.model_exact = std::move(me);
     if ((rc = upload_model(ctx, st.model_exact))) return fail(rc);
-    if (small_mix) {
-      // The small models (maps of 1 .. 32 pixels) miss the contract in the single pass -- but their time is in the FIRST stages (the
-      // large maps: layer0 + layer1 are 65 % of the 64 x 64 model's exact step) and their error in the LAST ones (nothing for the pooling
-      // to average on 1 .. 16 pixels).  Candidates: a set of stages in the single pass, the others exact (below); the admission rule of the
-      // 128 model.  No candidate -> exact.
-      CalibSession cal(ctx, st);
+    if (small_mix || st.calibrate) {
+      // The search itself lives in mlt_tier_search.h (no HIP in it; unit-tested on the CPU with a stub pricer):
+      //  128: single pass -> other realisations of the weights' rounding -> hi+lo weights in a subset of stages (cheapest first) -> some stages
+      //       exact -> refinements at launch-unit granularity -> exact;
+      //  64 / 32 / 16 (maps of 1 .. 32 pixels: their time is in the FIRST stages, their error in the LAST ones): the longest single-pass
+      //       prefix, layer0 with hi+lo weights, half of layer0 -> exact.  Largest error held to 0.5 x tolerance (their tails are heavier:
+      //       profiles/r04s_tail_probe_{64,32}.txt measured 1.5 .. 1.85 x the calibration set's largest error).
+      CalibSession cal(ctx, st, extra);
       if ((rc = cal.begin())) return fail(rc);
-      const int ns = st.model.n_stages;
-      const unsigned all = (1u << ns) - 1u;
-      static const char *force_k = tuning_env("MLT_SMALL_PREFIX");
-      bool ok = false;
-      // (the largest error is held to 0.5 x tolerance here, not 0.65: the small models' tails are heavier -- few pixels to average -- and
-      // their 491 k-logit tail probes measured 1.5 .. 1.85 x the calibration set's largest error, profiles/r04s_tail_probe_{64,32}.txt)
-      auto within = [&]() {
-        const float kk = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return kk * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.5f * ctx->tolerance;
-      };
-      static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
-      // Candidates: the single pass in stages 0 .. k-1, the exact arithmetic from stage k on, longest prefix (cheapest) first.  (All 30
-      // stage subsets were priced once for the 64 x 64 model, profiles/r04p_small_models_all_subsets.txt: a single-pass stage anywhere but
-      // in front leaves the LAST head -- 2 x 2 maps -- at rms 4.3 .. 7.6e-4, so only prefixes are tried.)  MLT_SMALL_PREFIX=k (tuning)
-      // prices exactly the prefix of k stages.
-      std::vector<std::pair<float, unsigned>> cand;  // (unused cost, mask of the exact stages)
-      for (int k = ns - 1; k >= 1; --k) cand.push_back({0.f, all & ~((1u << k) - 1u)});
-      if (force_k) {
-        const int k = std::atoi(force_k) < 1 ? 1 : std::atoi(force_k) > ns - 1 ? ns - 1 : std::atoi(force_k);
-        cand.assign(1, {0.f, all & ~((1u << k) - 1u)});
-      }
-      for (size_t ci = 0; ci < cand.size() && !ok; ++ci) {
-        const unsigned xm = cand[ci].second;
-        if ((rc = cal.price(0, units_of_stages(xm)))) return fail(rc);
-        ok = within() || force_k != nullptr;
-        if (ok) { st.x_mask = xm; st.x_units = units_of_stages(xm); }
-        if (!ok && !no_w2 && !(xm & 1u) && (xm | 1u) == all) {  // only layer0 off the exact arithmetic: also with hi+lo WEIGHTS there (the fused layer0 kernels on 32 x 32 maps)
-          if (!st.model_w2.on_device) {
-            mlt::Model mw;
-            if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
-            st.model_w2 = std::move(mw);
-            if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
-          }
-          if ((rc = cal.price(units_of_stages(1u), units_of_stages(xm)))) return fail(rc);
-          if ((ok = within())) { st.x_mask = xm; st.x_units = units_of_stages(xm); st.w2_mask = 1u; st.w2_units = units_of_stages(1u); st.w2 = true; }
-        }
-      }
-      if (!ok && !force_k) {
-        // ... and HALF of layer0 off the exact arithmetic (launch units: layer0.0 = stem + conv1 + conv2 + shortcut | layer0.1 = the identity
-        // block): what keeps the 64 x 64 model exact is the activation rounding of layer0's four rounding sites together
-        const unsigned rest = units_of_stages(all & ~1u);
-        static const unsigned half[2] = {0x2u, 0x1u};  // exact units of layer0: layer0.1 only (layer0.0 single pass) | layer0.0 only
-        for (int hh = 0; hh < 2 && !ok; ++hh) {
-          if ((rc = cal.price(0, rest | half[hh]))) return fail(rc);
-          if ((ok = within())) { st.x_units = rest | half[hh]; st.x_mask = all; }
-        }
-      }
-      if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
-      if (!ok) {  // run it exact
+      DevicePricer pricer(ctx, st, cal, blob, bytes, size);
+      mlt::TierRules rules;
+      rules.tolerance = ctx->tolerance;
+      rules.max_frac = small_mix ? 0.5f : 0.65f;
+      mlt::TierForce force;
+      force.rounding = env_int("MLT_ROUNDING"); force.w2_mask = env_int("MLT_W2_MASK"); force.x_mask = env_int("MLT_X_MASK");
+      force.w2_units = env_int("MLT_W2_UNITS"); force.small_prefix = env_int("MLT_SMALL_PREFIX");
+      force.no_roundings = tuning_env("MLT_NO_ROUNDINGS") != nullptr; force.no_w2 = tuning_env("MLT_NO_W2") != nullptr;
+      force.no_xmix = tuning_env("MLT_NO_XMIX") != nullptr; force.no_w2_units = tuning_env("MLT_NO_W2_UNITS") != nullptr;
+      force.no_x_units = tuning_env("MLT_NO_X_UNITS") != nullptr;
+      mlt::TierChoice ch;
+      rc = small_mix ? mlt::search_tier_small(pricer, rules, force, st.model.n_stages, ch) : mlt::search_tier_128(pricer, rules, force, mlt::MLT_N_ROUNDINGS, ch);
+      if (rc) return fail(rc);
+      st.calib_cus = cal.n_used; st.calib_caller_cus = cal.n_caller_used;
+      st.calib_rms = ch.price.rms; st.calib_max = ch.price.max;
+      if (ch.exact) {  // run it exact
+        free_model(st.model_w2); st.model_w2 = mlt::Model();
         free_model(st.model);
         st.model = std::move(st.model_exact);
         st.model_exact = mlt::Model();
         st.exact = true;
-      }
-    }
-    if (st.calibrate) {
-      CalibSession cal(ctx, st);
-      if ((rc = cal.begin())) return fail(rc);
-      if ((rc = cal.price(0))) return fail(rc);
-      // Admission: statistical, not a bound.  (i) 5.5 x the worst pooled rms over the content classes / heads of the calibration set (a
-      // Gaussian tail of 4e-8 per logit); (ii) the largest error seen on the 5040 logits <= 0.65 x tolerance (the tail probes found the largest of 295 k logits at 1.2 .. 1.7 x it); (iii) round 4 -- a set whose
-      // largest error exceeds 5 x its overall rms on this sample (a Gaussian sample of this size peaks at 3.8) has a heavy tail: its factor
-      // grows with that ratio (1.1 x ratio: continuous at 5) up to 6.5, the worst max / rms ratio the round-3 tail probe (295 k logits per
-      // weight set) observed.
-      auto within = [&]() {
-        const float k = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return k * st.calib_rms <= ctx->tolerance && st.calib_max <= 0.65f * ctx->tolerance;
-      };
-      // REFINEMENTS of an admitted configuration (dropping hi+lo weights stage by stage / unit by unit) are held to a stricter rule: a greedy
-      // search that keeps every drop that still passes walks the configuration to the edge of the criterion, and with up to a dozen marginal
-      // candidates tried the lucky ones get through.  Measured (profiles/r04m_tail_probe_units.txt: 295 k logits per set): with the plain
-      // rule the unit-level tiers sat at 5.5 x rms = 0.94 .. 1.0 x tolerance and one logit of seed 24 reached 1.09e-3; the largest error of
-      // 295 k logits is 1.2 .. 1.7 x the largest of the calibration set's 5040 -> a refinement must leave max <= 0.6 x and k x rms <= 0.95 x
-      // tolerance.
-      auto within_refined = [&]() {
-        const float k = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-        return k * st.calib_rms <= 0.95f * ctx->tolerance && st.calib_max <= 0.6f * ctx->tolerance;
-      };
-      static const char *force_mask = tuning_env("MLT_W2_MASK");  // tuning: price exactly this stage mask (even when the single pass would do)
-      // The single pass failed with the weights' default rounding: the same arithmetic with another REALISATION of the tap-diffused rounding
-      // (mlt_model.h: tap order of the diffusion, error carried across input channels or not -- every weight still within one ulp).  The
-      // realisations are draws of one error distribution (CPU emulation, scripts/emul_fast.py: the worst head's rms moves by +-25 % between
-      // them for one weight set, none is better on average), so a set a little over the line may have one under it -- and then runs the
-      // single pass at full speed instead of hi+lo weights in two or three stages.  Same admission rule; at most 5 more packings
-      // (~50 ms each), only for sets that fail.
-      static const bool no_roundings = tuning_env("MLT_NO_ROUNDINGS") != nullptr;
-      static const char *force_rounding = tuning_env("MLT_ROUNDING");
-      if ((!within() || force_rounding) && size == 128 && !no_roundings && !force_mask) {
-        // (how far a realisation is from the line: the larger of its two admission figures, relative to their limits)
-        auto score = [&]() {
-          const float k = std::min(6.5f, std::max(5.5f, 1.1f * cal.tail_ratio));
-          return std::max(k * st.calib_rms / ctx->tolerance, st.calib_max / (0.65f * ctx->tolerance));
-        };
-        float best_score = score();
-        int best_v = 0;
-        bool got = false;
-        for (int v = 1; v < mlt::MLT_N_ROUNDINGS && !got; ++v) {
-          if (force_rounding) v = std::atoi(force_rounding) < 0 ? 0 : std::atoi(force_rounding) >= mlt::MLT_N_ROUNDINGS ? mlt::MLT_N_ROUNDINGS - 1 : std::atoi(force_rounding);
-          mlt::Model mv;
-          if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_FAST, size, mv, err, v)) { ctx->err = "weights (rounding " + std::to_string(v) + "): " + err; return fail(MLT_ERR_WEIGHTS); }
-          if ((rc = upload_model(ctx, mv))) { free_model(mv); return fail(rc); }
-          std::swap(st.model, mv);              // price() runs st.model
-          rc = cal.price(0);
-          got = rc == MLT_OK && (within() || force_rounding != nullptr);
-          if (rc == MLT_OK && !got && score() < best_score) { best_score = score(); best_v = v; }
-          if (!got) std::swap(st.model, mv);    // back to the default rounding
-          free_model(mv);
-          if (rc) return fail(rc);
-          if (force_rounding) break;
-        }
-        if (!got) {
-          // None admits the single pass.  The tiers below keep SOME launch units on the single pass: they are searched on the realisation
-          // that came closest (seeds 11 / 13 / 24: one chain, or all of layer0, fewer on hi+lo weights than with the default realisation --
-          // profiles/r04v_rounding_tier_probe.txt)
-          if (best_v != 0) {
-            mlt::Model mv;
-            if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_FAST, size, mv, err, best_v)) { ctx->err = "weights (rounding): " + err; return fail(MLT_ERR_WEIGHTS); }
-            if ((rc = upload_model(ctx, mv))) { free_model(mv); return fail(rc); }
-            std::swap(st.model, mv);
-            free_model(mv);
-          }
-          if ((rc = cal.price(0))) return fail(rc);  // (calib figures and tail ratio of the kept realisation again)
-        }
-      }
-      if (!within() || force_mask) {
-        // Single-pass fp16 does not meet the contract for this weight set.  Middle tiers: hi+lo WEIGHTS on single fp16 activations (2 MFMAs
-        // per product on the W2 forms of the fused kernels -- a third copy of the weights, on the fast tiling; the weight rounding is what
-        // dominates the fast error), stage by stage: the two models' stages compose freely, the rounding errors of different layers are
-        // independent (their variances add), and on this chip a hi+lo stage costs what its MFMAs cost (the fused W2 kernels run at the
-        // ~1.2 PFLOP/s the power-limited chip sustains) -- so the calibration prices the 15 stage subsets in the order of their measured
-        // cost and keeps the CHEAPEST one that meets the contract.  Only the 128 model (the small models' error is activation rounding).
-        const float rms1 = st.calib_rms, max1 = st.calib_max;
-        static const bool no_w2 = tuning_env("MLT_NO_W2") != nullptr;
-        bool w2_ok = false;
-        if (size == 128 && !no_w2) {
-          mlt::Model mw;
-          if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, mw, err)) { ctx->err = "weights (hi+lo copy): " + err; return fail(MLT_ERR_WEIGHTS); }
-          st.model_w2 = std::move(mw);
-          if ((rc = upload_model(ctx, st.model_w2))) return fail(rc);
-          // added ms per 4096 CUs of a stage in hi+lo weights (measured, round 4, with the FP8 lo product in the 128- and 256-channel chains:
-          // profiles/r04m_lo8_ab.txt): layer0 0.88, layer1 0.63, layer2 0.98, layer3 0.86 -- the 15 subsets in the order of their sums
-          static const unsigned order[15] = {0x2, 0x8, 0x1, 0x4, 0xA, 0x3, 0x6, 0x9, 0xC, 0x5, 0xB, 0xE, 0x7, 0xD, 0xF};
-          for (int k = 0; k < 15 && !w2_ok; ++k) {
-            const unsigned mask = force_mask ? (unsigned)std::strtoul(force_mask, nullptr, 0) & 0xFu : order[k];
-            if (mask == 0) break;
-            if ((rc = cal.price(units_of_stages(mask)))) return fail(rc);
-            if ((w2_ok = within() || force_mask != nullptr)) { st.w2_mask = mask; st.w2_units = units_of_stages(mask); }  // (a forced mask is kept whatever it measures: knock-out timing builds)
-            if (force_mask) break;
-          }
-        }
-        // The tier below exact (round 4): hi+lo weights everywhere do not meet the contract -- what is left is the fp16 rounding of the
-        // ACTIVATIONS, spread evenly over the network's 18 rounding sites (scripts/act_stage_study.py: no site or stage dominates).  A stage in the
-        // exact arithmetic removes its share: the subsets of stages, cheapest first (added ms per 4096 CUs of an exact stage over its hi+lo-
-        // weights form: layer0 3.8, layer1 2.3, layer2 1.65, layer3 1.7; hi+lo weights everywhere 8.5 ms, exact everywhere 17.6).
-        static const bool no_xmix = tuning_env("MLT_NO_XMIX") != nullptr;
-        static const char *force_x = tuning_env("MLT_X_MASK");
-        if (!w2_ok && size == 128 && !no_w2 && !no_xmix && (!force_mask || force_x)) {
-          static const unsigned xorder[11] = {0x4, 0x8, 0x2, 0xC, 0x1, 0x6, 0xA, 0x5, 0x9, 0xE, 0x3};
-          for (int k = 0; k < 11 && !w2_ok; ++k) {
-            const unsigned xm = force_x ? (unsigned)std::strtoul(force_x, nullptr, 0) & 0xFu : xorder[k];
-            if (xm == 0 || xm == 0xFu) break;
-            if ((rc = cal.price(units_of_stages(0xFu & ~xm), units_of_stages(xm)))) return fail(rc);
-            if ((w2_ok = within() || force_x != nullptr)) { st.w2_mask = 0xFu & ~xm; st.w2_units = units_of_stages(st.w2_mask); st.x_mask = xm; st.x_units = units_of_stages(xm); }
-            if (force_x) break;
-          }
-          if (w2_ok && !force_x) {
-            // ... and with the exact stages in place, the other stages may not all need their hi+lo weights: drop them greedily, the most
-            // expensive first (layer2 0.98, layer0 0.88, layer3 0.86, layer1 0.63 ms), keeping a drop only if the contract still holds
-            static const int drop[4] = {2, 0, 3, 1};
-            float rms_k = st.calib_rms, max_k = st.calib_max;
-            for (int k = 0; k < 4; ++k) {
-              const unsigned bit = 1u << drop[k];
-              if (!(st.w2_mask & bit)) continue;
-              if ((rc = cal.price(units_of_stages(st.w2_mask & ~bit), st.x_units))) return fail(rc);
-              if (within_refined()) { st.w2_mask &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
-            }
-            st.w2_units = units_of_stages(st.w2_mask);
-            st.calib_rms = rms_k; st.calib_max = max_k;
-          }
-        }
-        // ... and at the granularity the kernels allow: each stage is two launch units (layer0.0 | layer0.1; stride-2 conv + shortcut | the
-        // three stride-1 convs), and the units of the two models compose as freely as the stages do.  Drop the hi+lo weights unit by unit, the
-        // largest saving first (measured ms per 4096 CUs of a unit's hi+lo form over what replaces it), keeping a drop only if the contract
-        // still holds.  (A stage whose two units are both back on the single pass runs the whole-stage kernel again.)
-        static const bool no_units = tuning_env("MLT_NO_W2_UNITS") != nullptr;
-        static const char *force_units = tuning_env("MLT_W2_UNITS");
-        if (w2_ok && size == 128 && !no_units && ((!force_mask && !force_x) || force_units)) {
-          if (force_units) {
-            st.w2_units = (unsigned)std::strtoul(force_units, nullptr, 0) & 0xFFu & ~st.x_units;
-            if ((rc = cal.price(st.w2_units, st.x_units))) return fail(rc);
-          } else {
-            static const int drop[8] = {3, 1, 7, 5, 0, 4, 6, 2};  // chain 64 | layer0.1 | chain 256 | chain 128 | layer0.0 | s2 64->128 | s2 128->256 | s2 32->64
-            float rms_k = st.calib_rms, max_k = st.calib_max;
-            for (int k = 0; k < 8; ++k) {
-              const unsigned bit = 1u << drop[k];
-              if (!(st.w2_units & bit)) continue;
-              // (layer2 / layer3: a single-pass stride-2 conv in front of a hi+lo-weights chain is not a legal pair -- its large launches
-              // would run the stand-alone single-pass kernel, whose accumulation order is not the one of its small-launch variant, which
-              // follows the whole-stage kernel: the entry points would differ in the last bits)
-              if ((drop[k] == 4 || drop[k] == 6) && ((st.w2_units | st.x_units) & (bit << 1))) continue;
-              if ((rc = cal.price(st.w2_units & ~bit, st.x_units))) return fail(rc);
-              if (within_refined()) { st.w2_units &= ~bit; rms_k = st.calib_rms; max_k = st.calib_max; }
-            }
-            st.calib_rms = rms_k; st.calib_max = max_k;
-          }
-          st.w2_mask = stages_of_units(st.w2_units);
-        }
-        // ... and the exact stages of the tier below exact, unit by unit: an exact unit goes back to its hi+lo-weights form (the stride-1
-        // chains first: 2.6 ms exact against 1.3 - 1.6 with hi+lo weights; then the stride-2 convs), under the refinement rule
-        static const bool no_xunits = tuning_env("MLT_NO_X_UNITS") != nullptr;
-        if (w2_ok && size == 128 && st.x_units && !no_xunits && !force_x && !force_mask && !force_units) {
-          static const int xdrop[8] = {3, 5, 7, 1, 2, 4, 6, 0};
-          float rms_k = st.calib_rms, max_k = st.calib_max;
-          for (int k = 0; k < 8; ++k) {
-            const unsigned bit = 1u << xdrop[k];
-            if (!(st.x_units & bit)) continue;
-            if ((rc = cal.price(st.w2_units | bit, st.x_units & ~bit))) return fail(rc);
-            if (within_refined()) { st.x_units &= ~bit; st.w2_units |= bit; rms_k = st.calib_rms; max_k = st.calib_max; }
-          }
-          st.calib_rms = rms_k; st.calib_max = max_k;
-          st.x_mask = stages_of_units(st.x_units);
-          st.w2_mask = stages_of_units(st.w2_units);
-        }
-        if (w2_ok) st.w2 = true;  // (calib_rms / calib_max now describe this tier)
-        else {  // run it exact
-          free_model(st.model_w2);
-          st.model_w2 = mlt::Model();
-          st.calib_rms = rms1; st.calib_max = max1;
-          free_model(st.model);
-          st.model = std::move(st.model_exact);
-          st.model_exact = mlt::Model();
-          st.exact = true;
-        }
+      } else {
+        st.w2 = ch.w2;
+        st.w2_units = ch.w2_units; st.x_units = ch.x_units;
+        st.w2_mask = mlt::stages_of_units(ch.w2_units); st.x_mask = mlt::stages_of_units(ch.x_units);
+        if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
       }
     }
   }
@@ -1340,8 +1199,103 @@ int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
   return MLT_OK;
 }
 
+// every device of a context: load / re-calibrate, then make sure they all landed on the SAME arithmetic (the header promises results
+// bit-identical to a one-device context); on any failure the size is unloaded everywhere (no mixed weight sets)
+int load_all(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const CalibExtra *extra) {
+  const int si = size_index(size);
+  if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
+  int rc = load_one(ctx, size, blob, bytes, extra);
+  for (size_t i = 0; i < ctx->peers.size() && rc == MLT_OK; ++i) {
+    mlt_ctx *p = ctx->peers[i];
+    rc = load_one(p, size, blob, bytes, extra);
+    if (rc) ctx->err = "device " + std::to_string(p->device) + ": " + p->err;
+    else {
+      const SizeState &a = ctx->sz[si], &b = p->sz[si];
+      if (a.exact != b.exact || a.w2 != b.w2 || a.w2_units != b.w2_units || a.x_units != b.x_units || a.model.rounding != b.model.rounding) {
+        ctx->err = "device " + std::to_string(p->device) + " calibrated to a different arithmetic than device " + std::to_string(ctx->device);
+        rc = MLT_ERR_WEIGHTS;
+      }
+    }
+  }
+  if (rc) {
+    unload_size(ctx, si);
+    for (mlt_ctx *p : ctx->peers) unload_size(p, si);
+    ctx->sz[si].blob.clear();
+  }
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int mlt_abi_version(void) { return MLT_ABI_VERSION; }
+
+int mlt_num_logits(int size) { return size == 128 ? 9 : (size == 64 || size == 32 || size == 16) ? 15 : 0; }
+
+const char *mlt_last_error(const mlt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes) {
+  if (!ctx || !blob) return MLT_ERR_ARG;
+  const int si = size_index(size);
+  if (si < 0) { ctx->err = "unsupported CU size"; return MLT_ERR_ARG; }
+  // the library keeps the blob (5.6 - 6.3 MB): mlt_calibrate re-packs from it
+  std::vector<char> keep((const char *)blob, (const char *)blob + bytes);
+  const int rc = load_all(ctx, size, keep.data(), keep.size(), nullptr);
+  if (rc == MLT_OK) ctx->sz[si].blob = std::move(keep);
+  return rc;
+}
+
+int mlt_calibrate(mlt_ctx *ctx, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp, int n, int mode) {
+  if (!ctx) return MLT_ERR_ARG;
+  if (!org || !pred || !poc || !qp || n <= 0 || n > kCalibCallerMax || (mode != MLT_CALIB_APPEND && mode != MLT_CALIB_REPLACE)) { ctx->err = "mlt_calibrate: bad argument"; return MLT_ERR_ARG; }
+  SizeState *st;
+  int rc = check_size(ctx, size, &st);
+  if (rc) return rc;
+  if (st->blob.empty()) { ctx->err = "mlt_calibrate: no weight blob kept for this size"; return MLT_ERR_WEIGHTS; }
+  if (!st->calibrate && !st->small_mix) return MLT_OK;  // configured exact / calibration switched off: nothing to decide
+  const CalibExtra ex{org, pred, poc, qp, n, mode == MLT_CALIB_REPLACE};
+  std::vector<char> keep = std::move(st->blob);  // (load_all clears the kept blob on failure)
+  rc = load_all(ctx, size, keep.data(), keep.size(), &ex);
+  if (rc == MLT_OK) ctx->sz[size_index(size)].blob = std::move(keep);
+  return rc;
+}
+
+// CPU test hook of the tier search (mlt_tier_search.h; not part of include/mltcnn.h): no HIP call on this path
+int mlt_tier_search_run(int kind, int n, float tolerance, float max_frac, const int *force,
+                        int (*price_cb)(void *user, unsigned w2_units, unsigned x_units, int rounding, float *out3), void *user, int *result, float *figures) {
+  if (!price_cb || !result || !figures || n <= 0) return MLT_ERR_ARG;
+  struct CbPricer : mlt::TierPricer {
+    int (*cb)(void *, unsigned, unsigned, int, float *); void *user;
+    int price(unsigned w2u, unsigned xu, int r, mlt::TierPrice &out) override {
+      float o[3] = {0.f, 0.f, 0.f};
+      const int rc = cb(user, w2u, xu, r, o);
+      out.rms = o[0]; out.max = o[1]; out.tail = o[2];
+      return rc;
+    }
+  } pricer;
+  pricer.cb = price_cb; pricer.user = user;
+  mlt::TierRules rules;
+  if (tolerance > 0.f) rules.tolerance = tolerance;
+  if (max_frac > 0.f) rules.max_frac = max_frac;
+  mlt::TierForce f;
+  if (force) {
+    f.rounding = force[0]; f.w2_mask = force[1]; f.x_mask = force[2]; f.w2_units = force[3]; f.small_prefix = force[4];
+    f.no_roundings = force[5] != 0; f.no_w2 = force[6] != 0; f.no_xmix = force[7] != 0; f.no_w2_units = force[8] != 0; f.no_x_units = force[9] != 0;
+  }
+  mlt::TierChoice ch;
+  const int rc = kind == 0 ? mlt::search_tier_128(pricer, rules, f, n, ch) : mlt::search_tier_small(pricer, rules, f, n, ch);
+  result[0] = ch.exact ? 1 : 0; result[1] = ch.w2 ? 1 : 0; result[2] = (int)ch.w2_units; result[3] = (int)ch.x_units; result[4] = ch.rounding; result[5] = ch.priced;
+  result[6] = result[7] = 0;
+  figures[0] = ch.price.rms; figures[1] = ch.price.max; figures[2] = ch.price.tail;
+  return rc;
+}
+
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   if (!ctx || !out) return MLT_ERR_ARG;
+  // the caller says how large ITS struct is; only that much is written (a later, longer mlt_arith_info cannot overrun an older caller)
+  if (out->struct_size < sizeof(mlt_arith_info)) { ctx->err = "mlt_arith_info.struct_size does not cover the ABI-4 fields"; return MLT_ERR_ARG; }
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
@@ -1357,6 +1311,7 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   out->flat_guard = (!st->exact && st->flat_guard) ? 1 : 0;
   out->decision_guard = (!st->exact && st->margin_guard) ? 1 : 0;
   out->guard_reruns = st->reruns;
+  out->calib_cus = st->calib_cus; out->calib_caller_cus = st->calib_caller_cus;
   return MLT_OK;
 }
 
@@ -1377,9 +1332,10 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
   ctx->device = device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
   if (cfg->tolerance > 0.f) ctx->tolerance = cfg->tolerance;
-  // decision guard: two logits that are each within `tolerance` of the reference change their difference by at most 2 x tolerance, so a
-  // top-2 margin of at least that much cannot flip -- everything below it is re-evaluated exactly
-  ctx->guard_margin = cfg->guard_margin > 0.f ? cfg->guard_margin : 2.f * ctx->tolerance;
+  // decision guard: two logits that are each within `tolerance` of the reference change their difference by at most 2 x tolerance.  The
+  // admission of the fast arithmetic is calibrated, not proven (the tail probes put single logits at up to ~1.1 x tolerance), so the
+  // default threshold is 3 x tolerance: everything below it is re-evaluated exactly (the extra re-runs are a fraction of a per cent)
+  ctx->guard_margin = cfg->guard_margin > 0.f ? cfg->guard_margin : 3.f * ctx->tolerance;
   if (const char *e = tuning_env("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
   if (const char *e = tuning_env("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
   if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
@@ -1417,7 +1373,7 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
     // precision: 128 -> fast (single fp16 pass) unless MLT_FLAG_EXACT_128; 64/32/16 -> exact (fp16 hi+lo pairs, 3 passes)
     // unless MLT_FLAG_FAST_SMALL.  See DESIGN.md "Numerics".
     st.want_exact = st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
-    st.margin_guard = (cfg->flags & MLT_FLAG_DECISION_GUARD) != 0;
+    st.margin_guard = (cfg->flags & MLT_FLAG_NO_DECISION_GUARD) == 0;  // ABI 4: on by default (MLT_FLAG_DECISION_GUARD is accepted and has no effect)
     st.flat_guard = (cfg->flags & MLT_FLAG_NO_FLAT_GUARD) == 0;
     // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
     st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
@@ -1452,10 +1408,11 @@ extern "C" {
 
 int mlt_init(const mlt_config *cfg, mlt_ctx **out) {
   std::lock_guard<std::mutex> lock(g_mutex);
-  // ABI 2 callers pass the 56-byte struct (no device list): accepted, one device
-  if (!cfg || !out || (cfg->struct_size != sizeof(mlt_config) && cfg->struct_size != MLT_CONFIG_SIZE_ABI2)) { g_init_error = "bad mlt_config"; return MLT_ERR_ARG; }
+  // ABI 4 is a hard break: older, shorter structs (the 56-byte ABI-2 mlt_config) are rejected -- such a binary would also pass a
+  // 32-byte mlt_arith_info to mlt_arithmetic
+  if (!cfg || !out || cfg->struct_size != sizeof(mlt_config)) { g_init_error = "bad mlt_config (struct_size does not match ABI 4)"; return MLT_ERR_ARG; }
   *out = nullptr;
-  const int nd = cfg->struct_size == sizeof(mlt_config) ? cfg->n_devices : 0;
+  const int nd = cfg->n_devices;
   if (nd < 0 || nd > MLT_MAX_DEVICES) { g_init_error = "bad mlt_config.n_devices"; return MLT_ERR_ARG; }
   mlt_ctx *ctx = nullptr;
   int rc = init_one(cfg, nd > 0 ? cfg->devices[0] : cfg->device, &ctx);
@@ -1514,6 +1471,8 @@ void mlt_shutdown(mlt_ctx *ctx) {
 
 int mlt_set_stream(mlt_ctx *ctx, void *hip_stream) {
   if (!ctx) return MLT_ERR_ARG;
+  // (a peer context handed out by mlt_device_ctx lives on another GPU than the current one: the replacement stream must be created there)
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   ctx->stream = nullptr;
@@ -1952,6 +1911,7 @@ void mlt_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
 
 int mlt_profile_enable(mlt_ctx *ctx, int on) {
   if (!ctx) return MLT_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (auto &kv : ctx->prof)
     for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1963,7 +1923,7 @@ int mlt_profile_enable(mlt_ctx *ctx, int on) {
 
 int mlt_profile_read(mlt_ctx *ctx, mlt_kernel_time *out, int cap) {
   if (!ctx) return -1;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
   int i = 0;
   for (const std::string &name : ctx->prof_order) {
     ProfAcc &acc = ctx->prof[name];

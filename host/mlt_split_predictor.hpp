@@ -11,9 +11,12 @@
 // Header-only; link with -lmltcnn_hip.  One instance per EncCu (the encoder is single-threaded, or one EncCu per
 // thread under WPP / split parallelism, EncCu.cpp:233).
 //
-// Decisions: the split mode is what the encoder consumes (EncCu.cpp:921 -> EncModeCtrl.cpp:110-149), so this class turns the library's
-// DECISION GUARD on by default (MLT_FLAG_DECISION_GUARD, margin 2 x tolerance): a CU whose decision-head top-2 margin is too small for
-// the fast arithmetic's error bound to guarantee the argmax is re-evaluated with the exact arithmetic before the call returns.
+// Decisions: the split mode is what the encoder consumes (EncCu.cpp:921 -> EncModeCtrl.cpp:110-149), so the library's DECISION GUARD is
+// on by default (ABI 4; margin 3 x tolerance; MLT_FLAG_NO_DECISION_GUARD turns it off): a CU whose decision-head top-2 margin is too
+// small for the fast arithmetic's calibrated error to leave the argmax alone is re-evaluated with the exact arithmetic before the call returns.
+//
+// MLTCNN_STATS=1 (any build): the destructor prints ONE line to stderr -- calls and wall-clock seconds inside predictSplitMode / submit /
+// flush / wait, calls per CU size -- the "share of an encode spent inside the predictor" figure tools/eval_harness.py reads (N4).
 //
 // Test hooks, compiled in only with -DMLTCNN_TEST_HOOKS (tools/build_vtm.sh does; a production build carries none of them):
 //   MLTCNN_FAULT_INJECT=1      the predictor reports ok() without touching a device and every predictSplitMode() fails (-1):
@@ -22,6 +25,7 @@
 //                              write(2) per record on an O_APPEND descriptor, so instances on several threads cannot interleave):
 //                              tests/test_vtm_encoder.py re-checks each one against the CPU oracle
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -43,9 +47,9 @@ class SplitPredictor {
  public:
   // weightsDir replaces the hard-coded "/home/ubuntu/whyeo/vtm-mlt-final/torch_model" (EncCu.cpp:899); files are
   // MLTORPQ_splitMode_<S>.mltw (tools/convert_weights.py).  sizeMask: MLT_SIZE_* bits (reference: 128 only, :754).
-  // flags: MLT_FLAG_* bits; the default turns the decision guard on (see above).  devices / nDevices: one predictor serving several GPUs
+  // flags: MLT_FLAG_* bits; 0 = the library's defaults (decision guard and flat guard on, see above).  devices / nDevices: one predictor serving several GPUs
   // (mlt_config.devices: batches submitted through submitSplitMode() are dealt round-robin); nullptr: `device`.
-  explicit SplitPredictor(const std::string &weightsDir, int device = 0, uint32_t sizeMask = MLT_SIZE_128, uint32_t flags = MLT_FLAG_DECISION_GUARD,
+  explicit SplitPredictor(const std::string &weightsDir, int device = 0, uint32_t sizeMask = MLT_SIZE_128, uint32_t flags = 0,
                           const int *devices = nullptr, int nDevices = 0) {
     mlt_config cfg{};
     cfg.struct_size = sizeof cfg;
@@ -56,9 +60,10 @@ class SplitPredictor {
     for (int &h : cfg.head_index) h = -1;  // reference defaults: element [2] for 128, [0] otherwise (EncCu.cpp:913-919)
     cfg.max_batch = 1;
     cfg.flags = flags;
-    cfg.guard_margin = 0.f;  // default threshold when MLT_FLAG_DECISION_GUARD is set
+    cfg.guard_margin = 0.f;  // the decision guard's default threshold (3 x tolerance)
     cfg.tolerance = 0.f;     // default |dlogit| contract (1e-3) for the load-time calibration of the fast arithmetic
     m_mask = sizeMask ? sizeMask : MLT_SIZE_128;
+    if (const char *s = std::getenv("MLTCNN_STATS")) m_stats = std::atoi(s) != 0;
 #ifdef MLTCNN_TEST_HOOKS
     if (const char *d = std::getenv("MLTCNN_CALL_DUMP_FILE")) m_dumpPath = d;
     if (const char *f = std::getenv("MLTCNN_FAULT_INJECT")) m_faultInject = std::atoi(f) != 0;
@@ -71,7 +76,13 @@ class SplitPredictor {
       m_ctx = nullptr;
     }
   }
-  ~SplitPredictor() { mlt_shutdown(m_ctx); }
+  ~SplitPredictor() {
+    if (m_stats)
+      std::fprintf(stderr, "mltcnn-stats predict_calls=%llu predict_s=%.6f submit_calls=%llu submit_s=%.6f wait_calls=%llu wait_s=%.6f flush_calls=%llu flush_s=%.6f "
+                           "calls_128=%llu calls_64=%llu calls_32=%llu calls_16=%llu failed=%llu\n",
+                   m_n[0], m_t[0], m_n[1], m_t[1], m_n[2], m_t[2], m_n[3], m_t[3], m_bySize[0], m_bySize[1], m_bySize[2], m_bySize[3], m_failed);
+    mlt_shutdown(m_ctx);
+  }
   SplitPredictor(const SplitPredictor &) = delete;
   SplitPredictor &operator=(const SplitPredictor &) = delete;
 
@@ -92,9 +103,11 @@ class SplitPredictor {
   int predictSplitMode(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, float *logitsOpt = nullptr) {
     int32_t split = -1;
     float lg[MLT_MAX_LOGITS] = {0};
+    Timer tm(this, 0, cuw);
     if (!m_ctx || mlt_predict(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, &split, (logitsOpt || !m_dumpPath.empty()) ? lg : nullptr) != MLT_OK) {
       std::fprintf(stderr, "error\n");  // EncCu.cpp:925
       split = -1;
+      ++m_failed;
     }
     if (logitsOpt) for (int i = 0; i < mlt_num_logits(cuw); ++i) logitsOpt[i] = lg[i];
     if (!m_dumpPath.empty()) dumpCall(org, orgStride, pred, predStride, cuw, poc, cuQP, split, lg);
@@ -107,11 +120,13 @@ class SplitPredictor {
   // call can be postponed together (e.g. the CTUs of a WPP anti-diagonal) the per-CU cost falls from ~150 us to
   // ~150 us / k (+ ~8 us).  At most MLT_DEFER_CAP CUs per batch; a full batch is launched by the next submit.
   bool submitSplitMode(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, mlt_ticket *ticket) {
+    Timer tm(this, 1, cuw);
     return m_ctx && mlt_submit(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, ticket) == MLT_OK;
   }
-  void flush(int cuw) { if (m_ctx) (void)mlt_flush(m_ctx, cuw); }  // start the batch early, e.g. before unrelated host work
+  void flush(int cuw) { Timer tm(this, 3, 0); if (m_ctx) (void)mlt_flush(m_ctx, cuw); }  // start the batch early, e.g. before unrelated host work
   int waitSplitMode(int cuw, mlt_ticket ticket, float *logitsOpt = nullptr) {
     int32_t split = -1;
+    Timer tm(this, 2, 0);
     if (!m_ctx || mlt_wait(m_ctx, cuw, ticket, &split, logitsOpt) != MLT_OK) return -1;
     return split;
   }
@@ -140,6 +155,20 @@ class SplitPredictor {
     (void)org; (void)orgStride; (void)pred; (void)predStride; (void)cuw; (void)poc; (void)cuQP; (void)split; (void)lg;
 #endif
   }
+
+  // MLTCNN_STATS: wall-clock inside the predictor, per entry point (0 predict, 1 submit, 2 wait, 3 flush)
+  struct Timer {
+    SplitPredictor *p; int k; std::chrono::steady_clock::time_point t0;
+    Timer(SplitPredictor *pp, int kk, int cuw) : p(pp->m_stats ? pp : nullptr), k(kk) {
+      if (!p) return;
+      t0 = std::chrono::steady_clock::now();
+      if (cuw) ++p->m_bySize[cuw == 128 ? 0 : cuw == 64 ? 1 : cuw == 32 ? 2 : 3];
+    }
+    ~Timer() { if (p) { p->m_t[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++p->m_n[k]; } }
+  };
+  bool m_stats = false;
+  unsigned long long m_n[4] = {0, 0, 0, 0}, m_bySize[4] = {0, 0, 0, 0}, m_failed = 0;
+  double m_t[4] = {0, 0, 0, 0};
 
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;

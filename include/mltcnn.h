@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MLT_ABI_VERSION 3
+#define MLT_ABI_VERSION 4
 
 enum {
   MLT_OK = 0,
@@ -45,24 +45,30 @@ enum {
  * fast : fp16 operands on the MFMA units, fp32 accumulate.  Its logit error depends on the weight set (rms 1.4e-4 ... 5.5e-4
  *        over seeded weight sets, tails ~4.5x rms) and on the content (exactly-constant areas carry coherent rounding errors).
  * exact: every weight / activation is an fp16 (hi, lo) pair, 3 MFMA passes, ~fp32 accuracy (|dlogit| ~ 1e-5).
- * Defaults: 128x128 -> fast WHEN the load-time calibration says the weight set meets mlt_config.tolerance with it (else
- * exact), 64/32/16 -> exact (few pixels per map, so fp16 rounding is not averaged away by the global pooling, and these
- * models are 5-65x cheaper).  Sizes that run the fast arithmetic are protected by two device-side guards, applied on
- * EVERY entry point (single, batch, device-pointer, deferred):
+ * Defaults: 128x128 -> fast WHEN the load-time calibration says the weight set meets mlt_config.tolerance with it (else a middle
+ * tier or exact, see mlt_load_weights); 64/32/16 -> CONFIGURED exact (few pixels per map, so fp16 rounding is not averaged away by the
+ * global pooling, and these models are 5-65x cheaper), but the same calibration may keep layer0 -- or one of its two launch units --
+ * on the single-pass or hi+lo-weights kernels when the contract still holds with it (mlt_arith_info.exact == 4, .x_units = what
+ * stays exact; admission as for the 128 model but with the largest error held to 0.5 x tolerance instead of 0.65 x: their tails are
+ * heavier).  Sizes with ANY non-exact unit are protected by two device-side guards (and keep a second, exact copy of the weights
+ * resident), applied on EVERY entry point (single, batch, device-pointer, deferred):
  *   flat guard (default on): CUs in which >= 1/8 of the aligned 4-pixel quads are EXACTLY FLAT (org and |org - pred| each constant or
  *                            exactly linear over the quad) or >= 1/2 are NEAR-FLAT (each spans <= 8 ten-bit steps or is linear to
  *                            within one step: +-1 LSB dither, low-contrast texture, ramps) are re-evaluated with the exact
  *                            arithmetic (their fp16 rounding errors are coherent, the global pooling does not average them away);
- *   decision guard (opt-in in this struct; ON by default in host/mlt_split_predictor.hpp, the encoder's path): CUs whose
- *                            decision-head top-2 margin is below guard_margin (default 2 x tolerance) are re-evaluated too, so
- *                            the split mode handed to EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
+ *   decision guard (default on since ABI 4 -- split modes are what the encoder consumes, EncCu.cpp:921 -> EncModeCtrl.cpp:110-149;
+ *                            MLT_FLAG_NO_DECISION_GUARD turns it off): CUs whose decision-head top-2 margin is below guard_margin
+ *                            (default 3 x tolerance) are re-evaluated too, so the split mode handed to
+ *                            EncModeCtrl::setNewModeList is the one ~fp32 arithmetic gives.
  * Both cost a second (exact) copy of the weights on the device (11 MB). */
 #define MLT_FLAG_EXACT_128 0x1u
 #define MLT_FLAG_FAST_SMALL 0x2u       /* single-pass fp16 for 64/32/16 (measurement only: NO seeded weight set meets 1e-3 with it --
                                           2e-3 ... 6e-3 measured -- and it is neither calibrated nor guarded) */
-#define MLT_FLAG_DECISION_GUARD 0x4u
+#define MLT_FLAG_DECISION_GUARD 0x4u    /* ABI <= 3: opt-in to the decision guard.  Since ABI 4 the guard is the default: accepted, no effect */
 #define MLT_FLAG_NO_FLAT_GUARD 0x8u    /* fast arithmetic without the flat-content guard (measurement only) */
 #define MLT_FLAG_NO_CALIBRATION 0x10u  /* keep the fast arithmetic whatever the weight set (measurement only) */
+#define MLT_FLAG_NO_DECISION_GUARD 0x20u /* ABI 4: fast arithmetic without the decision guard (measurement only: a split whose reference margin is
+                                          below ~2 x tolerance may then differ from the reference's) */
 
 typedef struct mlt_ctx mlt_ctx;
 
@@ -77,13 +83,15 @@ typedef struct mlt_config {
                              element [2] for 128, [0] otherwise (EncCu.cpp:913-919) */
   int32_t max_batch;      /* largest n passed to mlt_predict_batch*; 0 => 4096 */
   uint32_t flags;         /* MLT_FLAG_* bits, 0 = defaults */
-  float guard_margin;     /* MLT_FLAG_DECISION_GUARD threshold on (top1 - top2) of the decision head; <= 0 => 2 x tolerance: two logits
-                             that are each within `tolerance` of the reference move their difference by at most that much, so a
-                             larger margin cannot flip and everything below it is re-evaluated exactly */
+  float guard_margin;     /* decision-guard threshold on (top1 - top2) of the decision head; <= 0 => 3 x tolerance.  Two logits that are each
+                             within `tolerance` of the reference move their difference by at most 2 x tolerance; the admission of the fast
+                             arithmetic is CALIBRATED (statistical), not proven, and its tail probes saw single logits at up to ~1.1 x tolerance,
+                             hence 3 x rather than 2 x: everything below the threshold is re-evaluated exactly */
   float tolerance;        /* |dlogit| contract the fast arithmetic is calibrated against at load time; <= 0 => 1e-3
                              (BASELINE.json north_star) */
   uint32_t reserved;      /* 0 */
-  /* ---- ABI 3 (struct_size == sizeof(mlt_config); the 56-byte ABI-2 struct is still accepted: one device) ---- */
+  /* ---- since ABI 3.  ABI 4 is a hard break: struct_size must equal sizeof(mlt_config) (the 56-byte ABI-2 struct is rejected with
+     MLT_ERR_ARG -- an ABI-2 binary would also hand mlt_arithmetic a 32-byte mlt_arith_info) ---- */
   int32_t n_devices;      /* 0: the single `device` above.  k >= 1: devices[0..k-1] -- ONE context serving k GPUs of the node (SURVEY.md 8e
                              "CTUs within a frame shard across the GPUs"; the encoder is one process): weights are uploaded (and
                              calibrated) once per device from the one host blob, mlt_predict_batch shards its batch contiguously over the
@@ -95,7 +103,6 @@ typedef struct mlt_config {
   int32_t devices[8];
 } mlt_config;
 #define MLT_MAX_DEVICES 8
-#define MLT_CONFIG_SIZE_ABI2 56
 
 /* Create a context: selects the device, allocates workspaces, loads + folds + packs weights
  * ONCE (the reference re-reads the .pt on every CU, EncCu.cpp:894-900).  Natural home:
@@ -126,8 +133,11 @@ mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
  * admission is STATISTICAL (synthetic content, Gaussian-tail factor), not a bound: "within 1e-3" is calibrated, not proven. */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 
-/* Arithmetic a size runs after loading + what the calibration measured.  Any pointer may be NULL. */
+/* Arithmetic a size runs after loading + what the calibration measured.  The caller sets struct_size = sizeof(mlt_arith_info) BEFORE the
+ * call (ABI 4); the library writes only the fields that fit into struct_size bytes and fails with MLT_ERR_ARG when struct_size does not
+ * even cover the ABI-4 fields below, so a later, longer struct never overruns an older caller's storage. */
 typedef struct mlt_arith_info {
+  uint32_t struct_size;   /* in: sizeof(mlt_arith_info) of the caller */
   int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations in
                              every stage; 3: (hi, lo) weights in SOME stages (w2_stages), single pass in the others; 4: the exact arithmetic in the
                              stages of x_stages, (hi, lo) weights in the others (w2_stages) */
@@ -143,8 +153,23 @@ typedef struct mlt_arith_info {
                              bit 2 s + 1 = its second (layer0.1 / its three stride-1 convs) */
   int32_t x_units;        /* ABI 3: x_stages at the same launch-unit granularity */
   int32_t rounding;       /* ABI 3: which realisation of the single-pass weights' tap-diffused rounding the calibration kept (0 = the default) */
+  int32_t calib_cus;      /* ABI 4: CUs the last calibration priced (synthetic + caller's, without those the flat guard re-evaluates exactly anyway) */
+  int32_t calib_caller_cus; /* ABI 4: ... of which supplied by the caller through mlt_calibrate */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
+
+/* ABI 4: calibrate on the INTEGRATOR's content.  mlt_load_weights decides the arithmetic of a size on 560 synthetic CUs generated inside the
+ * library; this call repeats that decision -- the same admission rule, the same search (csrc/mlt_tier_search.h) -- with n CUs of the caller's
+ * (HOST memory, dense [n][size][size] int16 org / pred as in mlt_predict_batch, int32 poc / qp; e.g. what host/mlt_split_predictor.hpp's call
+ * dump recorded from real sequences: tools/calibrate_from_dump.py) APPENDED to the synthetic set (their own content class: the worst pooled
+ * rms over classes counts) or REPLACING it.  Caller CUs the flat-content guard re-evaluates exactly anyway are left out of the statistics
+ * (mlt_arith_info.calib_caller_cus = those that counted).  1 <= n <= 4096.  The size must have been loaded with mlt_load_weights / weights_dir
+ * (the library keeps the blob); sizes configured exact (MLT_FLAG_EXACT_128) or loaded with MLT_FLAG_NO_CALIBRATION are left alone.  Every
+ * device of a multi-device context is re-calibrated; like a reload it invalidates captured graphs, and the outcome is read with
+ * mlt_arithmetic.  On failure the size is unloaded (the caller keeps -1 / full RDO until it loads weights again). */
+#define MLT_CALIB_APPEND 0
+#define MLT_CALIB_REPLACE 1
+int mlt_calibrate(mlt_ctx *ctx, int size, const int16_t *org, const int16_t *pred, const int32_t *poc, const int32_t *qp, int n, int mode);
 
 /* Replaces EncCu.cpp:806-921 for ONE CU: gathers size x size luma from the original and the
  * prediction buffers (Pel = int16, element strides as AreaBuf exposes them, Buffer.h:94-105),

@@ -25,7 +25,7 @@ def test_exports_match_header(pkg, lib):
 
 
 def test_abi_version_and_logit_counts(lib):
-    assert lib.mlt_abi_version() == 3
+    assert lib.mlt_abi_version() == 4
     assert [lib.mlt_num_logits(s) for s in (128, 64, 32, 16, 8)] == [9, 15, 15, 15, 0]
 
 
@@ -35,8 +35,9 @@ def test_config_struct_layout(pkg):
     assert pkg.capi.MltConfig.n_devices.offset == 56 and pkg.capi.MltConfig.devices.offset == 60
     assert pkg.capi.MltConfig.guard_margin.offset == 44
     assert pkg.capi.MltConfig.tolerance.offset == 48
-    assert C.sizeof(pkg.capi.MltArithInfo) == 56   # ABI 3: + w2_stages, guard_margin, x_stages, w2_units, x_units, rounding
-    assert pkg.capi.MltArithInfo.w2_stages.offset == 32 and pkg.capi.MltArithInfo.guard_margin.offset == 36
+    assert C.sizeof(pkg.capi.MltArithInfo) == 72   # ABI 4: struct_size in front of the ABI-3 fields (the library writes only what fits)
+    assert pkg.capi.MltArithInfo.struct_size.offset == 0 and pkg.capi.MltArithInfo.guard_reruns.offset == 32
+    assert pkg.capi.MltArithInfo.w2_stages.offset == 40 and pkg.capi.MltArithInfo.guard_margin.offset == 44 and pkg.capi.MltArithInfo.rounding.offset == 60 and pkg.capi.MltArithInfo.calib_caller_cus.offset == 68
     assert pkg.capi.MltConfig.weights_dir.offset == 8
     assert pkg.capi.MltConfig.head_index.offset == 20
     assert C.sizeof(pkg.capi.MltKernelTime) == 72
@@ -51,8 +52,9 @@ def test_init_rejects_bad_config(pkg, lib):
 
 
 def test_device_list_and_abi2_struct_are_validated_before_any_device_is_touched(pkg, lib):
-    """ABI 3: mlt_config carries a device list.  The 56-byte ABI-2 struct is still accepted (it reaches the device check), a device count
-    beyond MLT_MAX_DEVICES is an argument error, and -- without a GPU -- a well-formed list fails with MLT_ERR_NO_DEVICE, not a crash."""
+    """mlt_config carries a device list (ABI 3).  ABI 4 is a hard break: the 56-byte ABI-2 struct is REJECTED (its binary would also hand
+    mlt_arithmetic a 32-byte mlt_arith_info), a device count beyond MLT_MAX_DEVICES is an argument error, and -- without a GPU -- a
+    well-formed list fails with MLT_ERR_NO_DEVICE, not a crash."""
     import torch
     h = C.c_void_p()
     cfg = pkg.capi.MltConfig()
@@ -62,13 +64,15 @@ def test_device_list_and_abi2_struct_are_validated_before_any_device_is_touched(
     cfg.n_devices = -1
     assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1
     assert lib.mlt_num_devices(None) == 0 and not lib.mlt_device_ctx(None, 0)
+    cfg.struct_size = 56                                      # an ABI-2 caller
+    cfg.n_devices = 0
+    assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 1        # MLT_ERR_ARG, before any device is touched
+    assert b"ABI 4" in lib.mlt_last_error(None)
+    cfg.struct_size = C.sizeof(pkg.capi.MltConfig)
     if not torch.cuda.is_available():
         cfg.n_devices = 2
         cfg.devices[0], cfg.devices[1] = 0, 1
         assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 2    # MLT_ERR_NO_DEVICE
-        cfg.struct_size = 56                                  # an ABI-2 caller: no device list, `device` decides
-        cfg.n_devices = 0
-        assert lib.mlt_init(C.byref(cfg), C.byref(h)) == 2
 
 
 def test_no_gpu_fails_loudly(pkg):

@@ -37,7 +37,7 @@ def test_cpp_host_mirror_builds_and_links(pkg, tmp_path):
            "-L" + os.path.dirname(lib), "-lmltcnn_hip", "-Wl,-rpath," + os.path.dirname(lib)]
     assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib"))
-    assert out.returncode == 0 and "abi 3, logits(128) 9, logits(32) 15" in out.stdout
+    assert out.returncode == 0 and "abi 4, logits(128) 9, logits(32) 15" in out.stdout
 
 
 def test_gate_truth_table_matches_the_reference_condition(pkg, tmp_path):

@@ -45,7 +45,34 @@ def parse_vtm_log(text: str) -> dict:
         out.update(time_user_s=float(m.group(1)), time_elapsed_s=float(m.group(2)))
     if "bitrate_kbps" not in out or "time_user_s" not in out:
         raise ValueError("not a complete VTM encoder log (summary block or Total Time line missing)")
+    out.update(parse_predictor_stats(text))
     return out
+
+
+_STATS = re.compile(r"^mltcnn-stats (.*)$", re.M)
+
+
+def parse_predictor_stats(text: str) -> dict:
+    """The one line host/mlt_split_predictor.hpp prints at encoder shutdown under MLTCNN_STATS=1: calls and wall-clock seconds inside
+    predictSplitMode / submit / wait / flush, calls per CU size.  -> {} when the log carries none (an anchor run)."""
+    m = _STATS.search(text)
+    if not m:
+        return {}
+    kv = dict(tok.split("=", 1) for tok in m.group(1).split() if "=" in tok)
+    calls = {k: int(kv.get(k + "_calls", 0)) for k in ("predict", "submit", "wait", "flush")}
+    secs = {k: float(kv.get(k + "_s", 0.0)) for k in ("predict", "submit", "wait", "flush")}
+    return {"cnn_calls": calls["predict"] + calls["submit"], "cnn_seconds": sum(secs.values()), "cnn_calls_by_entry": calls, "cnn_seconds_by_entry": secs,
+            "cnn_calls_by_size": {s: int(kv.get(f"calls_{s}", 0)) for s in (128, 64, 32, 16)}, "cnn_failed": int(kv.get("failed", 0))}
+
+
+def batch_histogram(batch_log_text: str) -> dict:
+    """MLTCNN_BATCH_LOG (one line per flushed anti-diagonal: 'poc P diagonal D ctus C probed K') -> {batch size: count}."""
+    hist: dict = {}
+    for ln in batch_log_text.splitlines():
+        tok = ln.split()
+        if len(tok) >= 8 and tok[0] == "poc" and tok[6] == "probed":
+            hist[int(tok[7])] = hist.get(int(tok[7]), 0) + 1
+    return dict(sorted(hist.items()))
 
 
 def _pchip_slopes(x, y):

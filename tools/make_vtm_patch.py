@@ -64,7 +64,7 @@ def patch_enccu_cpp(t):
                      "        const char *dir  = std::getenv( \"MLTCNN_WEIGHTS_DIR\" );   // holds MLTORPQ_splitMode_<S>.mltw\n"
                      "        const char *dev  = std::getenv( \"MLTCNN_DEVICE\" );\n"
                      "        const char *mask = std::getenv( \"MLTCNN_SIZE_MASK\" );     // MLT_SIZE_* bits; default: 128x128 only\n"
-                     "        const char *flg  = std::getenv( \"MLTCNN_FLAGS\" );         // MLT_FLAG_* bits; default: the decision guard (split modes are what the encoder consumes)\n"
+                     "        const char *flg  = std::getenv( \"MLTCNN_FLAGS\" );         // MLT_FLAG_* bits; default 0: the library's defaults (decision guard + flat guard on)\n"
                      "        const char *devs = std::getenv( \"MLTCNN_DEVICES\" );       // \"0,1,2,...\": ONE predictor over several GPUs (batched CUs are dealt round-robin)\n"
                      "        int devList[MLT_MAX_DEVICES], numDev = 0;\n"
                      "        for( const char *p = devs; p && *p && numDev < MLT_MAX_DEVICES; )\n"
@@ -75,7 +75,7 @@ def patch_enccu_cpp(t):
                      "        }\n"
                      "        m_cnnSplitPredictor = new mlt::SplitPredictor( dir ? dir : \"./torch_model\", dev ? std::atoi( dev ) : 0,\n"
                      "                                                     mask ? (uint32_t) std::strtoul( mask, nullptr, 0 ) : MLT_SIZE_128,\n"
-                     "                                                     flg ? (uint32_t) std::strtoul( flg, nullptr, 0 ) : MLT_FLAG_DECISION_GUARD,\n"
+                     "                                                     flg ? (uint32_t) std::strtoul( flg, nullptr, 0 ) : 0u,\n"
                      "                                                     numDev ? devList : nullptr, numDev );\n"
                      "    }\n\n}\n", "init")
     t = cut(t, "if (partitioner.chType == 0 && tempCS->slice->getSliceType() != I_SLICE)", "useCNN = true;",
@@ -139,8 +139,16 @@ def patch_encslice_cpp(t):
 # The encoder keeps ONE running set of per-row states in raster order (CABAC contexts, HMVP table, previous QP, palette predictor); in
 # diagonal order they are saved after every coded CTU and restored before the next CTU of that row.  The bitstream is the serial
 # encoder's, bit for bit (tests/test_vtm_encoder.py) -- the decisions are the same, only when the GPU computes them changes.
+# Round 5 (found with the reference's own random-access configuration on a 832 x 480 clip, tools/run_ra_eval.py): ONE more piece of encoder
+# state is carried from CTU to CTU in CODING order -- InterSearch's two motion-estimation seed lists (m_affMVList / m_uniMvList, reset once
+# per slice, EncSlice.cpp:1395-1396; the affine search extrapolates EVERY stored model to the current block wherever it lies,
+# InterSearch.cpp:4673-4720).  In raster order a row inherits them from the END of the row above, which a diagonal schedule has not coded
+# yet -- no schedule can reproduce that.  So, when the variable MLTCNN_BATCH is DEFINED (0 or 1) and entropy-coding sync is on, the lists
+# restart at every CTU row (the idea behind VTM's own EnsureWppBitEqual switch): MLTCNN_BATCH=0 is the serial encoder under that rule,
+# MLTCNN_BATCH=1 the diagonal schedule, which saves / restores the lists per row like the other row states -- bit-identical to each other;
+# without the variable the encoder is the N1 encoder, untouched.
 N3_FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "source/Lib/EncoderLib/EncModeCtrl.h",
-            "source/Lib/EncoderLib/EncSlice.cpp"]
+            "source/Lib/EncoderLib/EncSlice.cpp", "source/Lib/EncoderLib/InterSearch.h"]
 
 
 def n3_enccu_cpp(t):
@@ -217,6 +225,25 @@ def n3_encmodectrl_h(t):
                         "    void abortCTU() { m_ComprCUCtxList.clear(); }\n", "abortCTU")
 
 
+def n3_intersearch_h(t):
+    return replace_once(t, "  void resetUniMvList() { m_uniMvListIdx = 0; m_uniMvListSize = 0; }\n",
+                        "  void resetUniMvList() { m_uniMvListIdx = 0; m_uniMvListSize = 0; }\n"
+                        "  // SURVEY 8f N3 (probe and replay over WPP anti-diagonals): the two motion-estimation seed lists above are carried from CTU to CTU in\n"
+                        "  // coding order (the affine one is consulted whatever the position of its entries); a diagonal schedule saves / restores them per CTU row\n"
+                        "  struct MeSeedLists { std::vector<AffineMVInfo> aff; std::vector<BlkUniMvInfo> uni; int affIdx = 0, affSize = 0, uniIdx = 0, uniSize = 0; };\n"
+                        "  void saveMeSeedLists( MeSeedLists &s ) const\n"
+                        "  {\n"
+                        "    s.aff.assign( m_affMVList, m_affMVList + m_affMVListMaxSize ); s.affIdx = m_affMVListIdx; s.affSize = m_affMVListSize;\n"
+                        "    s.uni.assign( m_uniMvList, m_uniMvList + m_uniMvListMaxSize ); s.uniIdx = m_uniMvListIdx; s.uniSize = m_uniMvListSize;\n"
+                        "  }\n"
+                        "  void restoreMeSeedLists( const MeSeedLists &s )\n"
+                        "  {\n"
+                        "    if( (int) s.aff.size() != m_affMVListMaxSize || (int) s.uni.size() != m_uniMvListMaxSize ) { resetAffineMVList(); resetUniMvList(); return; }\n"
+                        "    std::copy( s.aff.begin(), s.aff.end(), m_affMVList ); m_affMVListIdx = s.affIdx; m_affMVListSize = s.affSize;\n"
+                        "    std::copy( s.uni.begin(), s.uni.end(), m_uniMvList ); m_uniMvListIdx = s.uniIdx; m_uniMvListSize = s.uniSize;\n"
+                        "  }\n", "ME seed lists")
+
+
 def n3_encslice_cpp(t):
     t = replace_once(t,
                      "  // for every CTU in the slice\n  for( uint32_t ctuIdx = 0; ctuIdx < pcSlice->getNumCtuInSlice(); ctuIdx++ )\n  {\n"
@@ -227,6 +254,12 @@ def n3_encslice_cpp(t):
                      "  // 1 = probe (submit the 128x128 CU's planes to the CNN, abandon the CTU), 2 = flush the submitted CUs as one batch.\n"
                      "  const uint32_t heightInCtus = pcv.heightInCtus;\n"
                      "  static const bool cnnBatchEnv = std::getenv( \"MLTCNN_BATCH\" ) && std::atoi( std::getenv( \"MLTCNN_BATCH\" ) ) != 0;\n"
+                     "  // MLTCNN_BATCH defined (0 or 1) + entropy-coding sync: InterSearch's motion-estimation seed lists (reset once per slice upstream,\n"
+                     "  // EncSlice.cpp:1395-1396, and carried across CTU rows in raster order) restart at every CTU row, so that a row's encode depends only on\n"
+                     "  // the rows above it.  MLTCNN_BATCH=0 is the serial encoder under this rule -- the leg the diagonal schedule (MLTCNN_BATCH=1) is\n"
+                     "  // bit-identical to; without the variable nothing changes.\n"
+                     "  static const bool cnnRowRule = std::getenv( \"MLTCNN_BATCH\" ) != nullptr;\n"
+                     "  const bool cnnRowReset = cnnRowRule && pEncLib->getEntropyCodingSyncEnabledFlag();\n"
                      "  const bool cnnBatch = cnnBatchEnv && pEncLib->getEntropyCodingSyncEnabledFlag() && !pcSlice->isIntra() && cs.pps->getNumTiles() == 1\n"
                      "                        && pcSlice->getNumCtuInSlice() == widthInCtus * heightInCtus && pcSlice->getCtuAddrInSlice( 0 ) == 0\n"
                      "                        && !pCfg->getUseRateCtrl() && !pCfg->getUsePerceptQPA() && m_pcCuEncoder->cnnBatchingAvailable();\n"
@@ -256,6 +289,8 @@ def n3_encslice_cpp(t):
                      "  std::vector<LutMotionCand> rowLut( cnnBatch ? heightInCtus : 0 );\n"
                      "  std::vector<PLTBuf>        rowPLT( cnnBatch ? heightInCtus : 0 );\n"
                      "  std::vector<int>           rowPrevQP( cnnBatch ? 2 * heightInCtus : 0 );\n"
+                     "  std::vector<InterSearch::MeSeedLists> rowMe( cnnBatch ? heightInCtus : 0 );\n"
+                     "  InterSearch *cnnInterSearch = pEncLib->getInterSearch();\n"
                      "\n"
                      "  // for every CTU in the slice\n  for( size_t schedIdx = 0; schedIdx < sched.size(); schedIdx++ )\n  {\n"
                      "    const uint32_t ctuIdx   = sched[schedIdx].first;\n"
@@ -272,7 +307,9 @@ def n3_encslice_cpp(t):
                      "      cs.motionLut           = rowLut[ctuYPosInCtus];\n"
                      "      cs.setPrevPLT( rowPLT[ctuYPosInCtus] );\n"
                      "      prevQP[0] = rowPrevQP[2 * ctuYPosInCtus]; prevQP[1] = rowPrevQP[2 * ctuYPosInCtus + 1];\n"
-                     "    }\n\n"
+                     "      cnnInterSearch->restoreMeSeedLists( rowMe[ctuYPosInCtus] );\n"
+                     "    }\n"
+                     "    if( cnnRowReset && ctuXPosInCtus == 0 ) { cnnInterSearch->resetAffineMVList(); cnnInterSearch->resetUniMvList(); }\n\n"
                      "    if( pCfg->getSwitchPOC() != pcPic->poc || -1 == pCfg->getDebugCTU() )\n", "row state restore")
     t = replace_once(t,
                      "  if (pCfg->getSwitchPOC() != pcPic->poc || ctuRsAddr >= pCfg->getDebugCTU())\n    m_pcCuEncoder->compressCtu( cs, ctuArea, ctuRsAddr, prevQP, currQP );\n",
@@ -294,12 +331,13 @@ def n3_encslice_cpp(t):
                      "      rowLut[ctuYPosInCtus] = cs.motionLut;\n"
                      "      cs.storePrevPLT( rowPLT[ctuYPosInCtus] );\n"
                      "      rowPrevQP[2 * ctuYPosInCtus] = prevQP[0]; rowPrevQP[2 * ctuYPosInCtus + 1] = prevQP[1];\n"
+                     "      cnnInterSearch->saveMeSeedLists( rowMe[ctuYPosInCtus] );\n"
                      "    }\n"
                      "    // for last Ctu in the slice\n", "row state save")
     return t
 
 
-N3_PATCHERS = {N3_FILES[0]: n3_enccu_cpp, N3_FILES[1]: n3_enccu_h, N3_FILES[2]: n3_encmodectrl_h, N3_FILES[3]: n3_encslice_cpp}
+N3_PATCHERS = {N3_FILES[0]: n3_enccu_cpp, N3_FILES[1]: n3_enccu_h, N3_FILES[2]: n3_encmodectrl_h, N3_FILES[3]: n3_encslice_cpp, N3_FILES[4]: n3_intersearch_h}
 
 PATCHERS = {FILES[0]: patch_enccu_cpp, FILES[1]: patch_enccu_h, FILES[2]: patch_top_cmake, FILES[3]: patch_lib_cmake, FILES[4]: patch_encslice_cpp}
 
