@@ -21,6 +21,9 @@
 // Test hooks, compiled in only with -DMLTCNN_TEST_HOOKS (tools/build_vtm.sh does; a production build carries none of them):
 //   MLTCNN_FAULT_INJECT=1      the predictor reports ok() without touching a device and every predictSplitMode() fails (-1):
 //                              exercises the reference's swallow-and-continue contract from the real call site on a box without a GPU
+//   MLTCNN_FORCE_SPLIT=k       (with MLTCNN_FAULT_INJECT=1) every prediction "succeeds" with split mode k instead of failing: real, decision-
+//                              dependent encoder paths (EncModeCtrl::setNewModeList, EncModeCtrl.cpp:110-149) on a box without a GPU -- how
+//                              the probe-and-replay schedule is debugged against the serial encoder in the build container
 //   MLTCNN_CALL_DUMP_FILE=path every predictSplitMode() call is appended to `path` (little-endian records, see dumpCall; one
 //                              write(2) per record on an O_APPEND descriptor, so instances on several threads cannot interleave):
 //                              tests/test_vtm_encoder.py re-checks each one against the CPU oracle
@@ -67,6 +70,7 @@ class SplitPredictor {
 #ifdef MLTCNN_TEST_HOOKS
     if (const char *d = std::getenv("MLTCNN_CALL_DUMP_FILE")) m_dumpPath = d;
     if (const char *f = std::getenv("MLTCNN_FAULT_INJECT")) m_faultInject = std::atoi(f) != 0;
+    if (const char *f = std::getenv("MLTCNN_FORCE_SPLIT")) m_forceSplit = std::atoi(f);
     if (m_faultInject) return;
 #endif
     const int rc = mlt_init(&cfg, &m_ctx);
@@ -104,6 +108,7 @@ class SplitPredictor {
     int32_t split = -1;
     float lg[MLT_MAX_LOGITS] = {0};
     Timer tm(this, 0, cuw);
+    if (m_faultInject && m_forceSplit >= 0) return m_forceSplit;
     if (!m_ctx || mlt_predict(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, &split, (logitsOpt || !m_dumpPath.empty()) ? lg : nullptr) != MLT_OK) {
       std::fprintf(stderr, "error\n");  // EncCu.cpp:925
       split = -1;
@@ -121,12 +126,14 @@ class SplitPredictor {
   // ~150 us / k (+ ~8 us).  At most MLT_DEFER_CAP CUs per batch; a full batch is launched by the next submit.
   bool submitSplitMode(const Pel *org, int orgStride, const Pel *pred, int predStride, int cuw, int poc, int cuQP, mlt_ticket *ticket) {
     Timer tm(this, 1, cuw);
+    if (m_faultInject && m_forceSplit >= 0) { *ticket = 0; return true; }
     return m_ctx && mlt_submit(m_ctx, org, orgStride, pred, predStride, cuw, poc, cuQP, ticket) == MLT_OK;
   }
   void flush(int cuw) { Timer tm(this, 3, 0); if (m_ctx) (void)mlt_flush(m_ctx, cuw); }  // start the batch early, e.g. before unrelated host work
   int waitSplitMode(int cuw, mlt_ticket ticket, float *logitsOpt = nullptr) {
     int32_t split = -1;
     Timer tm(this, 2, 0);
+    if (m_faultInject && m_forceSplit >= 0) return m_forceSplit;
     if (!m_ctx || mlt_wait(m_ctx, cuw, ticket, &split, logitsOpt) != MLT_OK) return -1;
     return split;
   }
@@ -173,6 +180,7 @@ class SplitPredictor {
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;
   bool m_faultInject = false;   // (only ever set with MLTCNN_TEST_HOOKS)
+  int m_forceSplit = -1;        // (only ever set with MLTCNN_TEST_HOOKS)
   mutable bool m_dumpFailed = false;
   std::string m_dumpPath;
 };

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--n-texture", type=int, default=16384)
     ap.add_argument("--size", type=int, default=128, help="CU size (round 4: the small models' calibrated tiers too)")
+    ap.add_argument("--blobs", default="", help="comma list of MLTW files probed like seeds (round 5: tools/train_synth_weights.py's trained family)")
+    ap.add_argument("--natural", type=int, default=0, help="also N CUs of the natural-statistics class (synth.natural_patches)")
     a = ap.parse_args()
     pkg = mltcnn_pkg.load()
     S, size = pkg.synth, a.size
@@ -27,6 +29,10 @@ def main():
     classes = [("texture", None), ("uniform", S.KIND_UNIFORM), ("org_flat_pred_tex", S.KIND_ORG_FLAT_PRED_TEX),
                ("org_tex_pred_flat", S.KIND_ORG_TEX_PRED_FLAT), ("partial_flat", S.KIND_PARTIAL_FLAT)]
     data = {}
+    if a.natural:
+        org, pred = S.natural_patches(size, a.natural, 31337)
+        poc, qp = S.make_scalars(a.natural, 31337 + 99)
+        data["natural"] = (org, pred, poc, qp)
     for name, kind in classes:
         n = a.n_texture if kind is None else a.n
         org, pred = S.make_patches_bulk(size, n, 31337) if kind is None else S.make_patches(size, n, 31337 + kind, kind)
@@ -35,8 +41,10 @@ def main():
         print(f"generated {name}: {n} CUs", flush=True)
     heads = [slice(0, 2), slice(2, 5), slice(5, 9)] if size == 128 else [slice(0, 2), slice(2, 5), slice(5, 9), slice(9, 15)]
     dec = 2 if size == 128 else 0  # decision head (EncCu.cpp:913-919)
-    for seed in [int(v) for v in a.seeds.split(",")]:
-        blob = pkg.weights.synthetic_blob(arch, seed)
+    if a.natural:
+        classes = classes + [("natural", -1)]
+    for seed in [int(v) for v in a.seeds.split(",") if v] + [b for b in a.blobs.split(",") if b]:
+        blob = open(seed, "rb").read() if isinstance(seed, str) else pkg.weights.synthetic_blob(arch, seed)
         m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob})
         e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128 if size == 128 else pkg.capi.FLAG_NO_CALIBRATION)
         ar = m.arithmetic(size)

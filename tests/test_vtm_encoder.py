@@ -41,7 +41,7 @@ def _a_failed_encoder_build_is_a_failure_not_a_skip():
 def _env(**extra):
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "fastintercu-vvc_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
-    for k in ("MLTCNN_FAULT_INJECT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS", "MLTCNN_DEVICES", "MLTCNN_BATCH", "MLTCNN_BATCH_LOG"):
+    for k in ("MLTCNN_FAULT_INJECT", "MLTCNN_FORCE_SPLIT", "MLTCNN_STATS", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS", "MLTCNN_DEVICES", "MLTCNN_BATCH", "MLTCNN_BATCH_LOG"):
         env.pop(k, None)
     env.update(extra)
     return env
@@ -101,7 +101,8 @@ def test_probe_and_replay_over_wpp_diagonals_writes_the_serial_bitstream(tmp_pat
     tmp = str(tmp_path)
     yuv = _yuv(tmp)
     log = os.path.join(tmp, "batch.log")
-    runs = {"serial": _env(MLTCNN_FAULT_INJECT="1"), "batch": _env(MLTCNN_FAULT_INJECT="1", MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)}
+    # (MLTCNN_BATCH=0: the serial encoder under the per-row rule for InterSearch's motion-estimation seed lists -- round 5)
+    runs = {"serial": _env(MLTCNN_FAULT_INJECT="1", MLTCNN_BATCH="0"), "batch": _env(MLTCNN_FAULT_INJECT="1", MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)}
     procs = {k: subprocess.Popen(_encode_cmd(yuv, k, tmp) + ["--WaveFrontSynchro=1"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for k, e in runs.items()}
     logs = {k: p.communicate(timeout=900)[0] for k, p in procs.items()}
@@ -195,7 +196,7 @@ def test_probe_and_replay_batches_real_decisions_on_the_gpu(pkg, tmp_path):
     out = {}
     # "batch2": the same through ONE predictor over two device contexts (MLTCNN_DEVICES: mlt_config.devices[], batched CUs dealt round-robin;
     # both on ordinal 0 here -- a 1-GPU box -- the path an 8-GPU node takes with MLTCNN_DEVICES=0,1,...,7)
-    for tag, env in (("serial", _env(MLTCNN_WEIGHTS_DIR=wdir)), ("batch", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)),
+    for tag, env in (("serial", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="0")), ("batch", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=log)),
                      ("batch2", _env(MLTCNN_WEIGHTS_DIR=wdir, MLTCNN_BATCH="1", MLTCNN_DEVICES="0,0"))):
         r = subprocess.run(cmd(tag), env=env, capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -206,3 +207,58 @@ def test_probe_and_replay_batches_real_decisions_on_the_gpu(pkg, tmp_path):
     print(f"probe and replay on the GPU: {len(sizes)} batches over {FRAMES - 1} inter pictures, sizes {sorted(set(sizes))}, {sum(sizes)} CUs; bitstream == serial")
     assert max(sizes) >= 3 and sum(sizes) == (FRAMES - 1) * 32
     _decode_matches_recon(tmp, "batch")
+
+
+REF_RA_CFG = "/root/reference/vtm-mlt-cpp/cfg/encoder_randomaccess_vtm.cfg"
+
+
+def _run_ra_eval(tmp, mode, width, height, frames, extra=()):
+    import json
+    out = os.path.join(tmp, "ra_eval")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_ra_eval.py"), "--mode", mode, "--out", out, "--width", str(width), "--height", str(height),
+                        "--frames", str(frames), "--qps", "32", *extra], capture_output=True, text=True, timeout=3000, cwd=ROOT)
+    assert os.path.exists(os.path.join(out, "summary.json")), r.stdout[-3000:] + r.stderr[-3000:]
+    summ = json.load(open(os.path.join(out, "summary.json")))
+    return r, summ
+
+
+@pytest.mark.skipif(not os.path.exists(REF_RA_CFG), reason="the reference's cfg/encoder_randomaccess_vtm.cfg is not mounted (build container only)")
+def test_the_references_ra_configuration_holds_n1_and_n3(tmp_path):
+    """Round 5: the REFERENCE's own evaluation configuration -- cfg/encoder_randomaccess_vtm.cfg: GOP 32 `:15`, CTU 128
+    `:112`, MTT depth 3 `:119`, BIO / CIIP / Geo `:139-141`, LMCS `:145`, DMVR `:151`, plus SBT / MTS / BCW / SMVD / ALF / temporal filter --
+    on a clip with partial CTUs on both borders, every inference failing by fault injection (tools/run_ra_eval.py --mode cpu):
+    N1: bitstream(every predictSplitMode() = -1) == bitstream(no CU size enabled = stock RDO); N3: bitstream(MLTCNN_BATCH=1: probe and
+    replay over anti-diagonals) == bitstream(MLTCNN_BATCH=0) under WaveFrontSynchro=1, decodable to the encoder's reconstruction.
+    Reduced size here (448 x 320, 9 frames, ~1 min); MLT_RA_FULL=1 runs the 832 x 480, 17-frame clip whose results are committed in
+    profiles/r05_ra_eval_cpu/ -- the size at which InterSearch's motion-estimation seed lists first broke the diagonal schedule."""
+    full = os.environ.get("MLT_RA_FULL") == "1"
+    r, summ = _run_ra_eval(str(tmp_path), "cpu", 832 if full else 448, 480 if full else 320, 17 if full else 9, ("--jobs", "6", "--force-splits", "2"))
+    assert summ["cfg"] == REF_RA_CFG and summ["ok"] and r.returncode == 0, summ["checks"]
+    c = summ["checks"]["32"]
+    assert c["n1_inject_equals_anchor"] and c["n3_batch_equals_serial"] and c["batch_decodes_to_recon"]
+    # ... and with every prediction "succeeding" with BT_H (test hook MLTCNN_FORCE_SPLIT): the decision-dependent paths behind setNewModeList
+    assert c["n3_batch_equals_serial_forced_split_2"] and c["forced_split_2_differs_from_full_rdo"]
+    assert c["inject_hello_count"] >= 8 * 6          # every gated CU of every inter picture reached setNewModeList(-1)
+    assert sum(int(k) * v for k, v in c["batch_histogram"].items()) == c["inject_hello_count"] and max(int(k) for k in c["batch_histogram"]) >= 2
+
+
+@pytest.mark.gpu
+def test_ra_tool_set_on_the_gpu_all_four_cu_sizes_from_the_real_call_site(pkg, tmp_path):
+    """The same tool set (tests/data/vtm_ra_tools.cfg, written by tools/make_ra_cfg.py -- the reference tree does not exist on the GPU box) with
+    REAL decisions from seeded weights (tools/run_ra_eval.py --mode gpu, reduced clip): batched == serial bitstream under WPP; every call of
+    the 128-only encode and of the MLTCNN_SIZE_MASK=0xF encode -- the sub-128 call sites the reference has commented out (EncCu.cpp:754), head
+    [0] (`:913-919`), recursion through xCheckModeSplit -- matches the CPU oracle (|dlogit| <= 1e-3, every decisive split); mlt_calibrate
+    accepts the dump.  The full-size run (832 x 480 x 17, four QPs) is profiles/r05_ra_eval_gpu/."""
+    import torch
+    assert torch.cuda.is_available()
+    r, summ = _run_ra_eval(str(tmp_path), "gpu", 448, 320, 5)
+    print(r.stdout[-2500:])
+    assert summ["ok"] and r.returncode == 0, summ["checks"]
+    assert summ["checks"]["32"]["n3_batch_equals_serial"] and summ["checks"]["32"]["batch_decodes_to_recon"]
+    sizes = summ["checks"]["allsizes"]
+    assert set(sizes) == {"128", "64", "32", "16"}
+    for s, v in sizes.items():
+        assert v["calls"] >= 1 and v["within_tolerance"] and v["split_mismatch_decisive"] == 0, (s, v)
+    assert summ["checks"]["calibrate_on_the_dump"]["append"]["after"]["calib_caller_cus"] >= 1
+    rows = {(x["leg"], x["qp"]): x for x in summ["rows"]}
+    assert rows[("serial", 32)]["cnn_calls"] >= 6 and rows[("serial", 32)]["cnn_seconds"] > 0

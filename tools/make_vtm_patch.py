@@ -143,9 +143,12 @@ def patch_encslice_cpp(t):
 # state is carried from CTU to CTU in CODING order -- InterSearch's two motion-estimation seed lists (m_affMVList / m_uniMvList, reset once
 # per slice, EncSlice.cpp:1395-1396; the affine search extrapolates EVERY stored model to the current block wherever it lies,
 # InterSearch.cpp:4673-4720).  In raster order a row inherits them from the END of the row above, which a diagonal schedule has not coded
-# yet -- no schedule can reproduce that.  So, when the variable MLTCNN_BATCH is DEFINED (0 or 1) and entropy-coding sync is on, the lists
-# restart at every CTU row (the idea behind VTM's own EnsureWppBitEqual switch): MLTCNN_BATCH=0 is the serial encoder under that rule,
-# MLTCNN_BATCH=1 the diagonal schedule, which saves / restores the lists per row like the other row states -- bit-identical to each other;
+# yet -- no schedule can reproduce that.  The same holds for the GLOBAL uni-MV reuse cache g_reusedUniMVs / g_isReusedUniMVsFilled (Rom.cpp:709-710;
+# found with real, forced decisions at QP 27): keyed by the position INSIDE the CTU and cleared once per slice (EncSlice.cpp:1397), so a CU inherits
+# motion vectors from the CU at the same in-CTU position of the previously CODED CTU (InterSearch.cpp:2455-2458 -> EncModeCtrl.cpp:1899-1906).
+# So, when the variable MLTCNN_BATCH is DEFINED (0 or 1) and entropy-coding sync is on, the lists
+# and the reuse cache restart at every CTU row (the idea behind VTM's own EnsureWppBitEqual switch): MLTCNN_BATCH=0 is the serial encoder under
+# that rule, MLTCNN_BATCH=1 the diagonal schedule, which saves / restores them per row like the other row states -- bit-identical to each other;
 # without the variable the encoder is the N1 encoder, untouched.
 N3_FILES = ["source/Lib/EncoderLib/EncCu.cpp", "source/Lib/EncoderLib/EncCu.h", "source/Lib/EncoderLib/EncModeCtrl.h",
             "source/Lib/EncoderLib/EncSlice.cpp", "source/Lib/EncoderLib/InterSearch.h"]
@@ -291,6 +294,22 @@ def n3_encslice_cpp(t):
                      "  std::vector<int>           rowPrevQP( cnnBatch ? 2 * heightInCtus : 0 );\n"
                      "  std::vector<InterSearch::MeSeedLists> rowMe( cnnBatch ? heightInCtus : 0 );\n"
                      "  InterSearch *cnnInterSearch = pEncLib->getInterSearch();\n"
+                     "  // ... and the GLOBAL uni-MV reuse cache (Rom.cpp:709-710; written by InterSearch.cpp:2455-2458, read by EncModeCtrl.cpp:1899-1906): keyed by the\n"
+                     "  // position INSIDE the CTU and cleared once per slice (EncSlice.cpp:1397) -- a CU inherits the motion vectors the CU at the same in-CTU\n"
+                     "  // position of the PREVIOUSLY CODED CTU left behind.  Saved sparsely (the filled entries only) per CTU row.\n"
+                     "  struct CnnReusedMvs { std::vector<uint32_t> idx; std::vector<Mv> mvs; };\n"
+                     "  std::vector<CnnReusedMvs> rowReused( cnnBatch ? heightInCtus : 0 );\n"
+                     "  constexpr size_t cnnReuseSlots = sizeof( g_isReusedUniMVsFilled ) / sizeof( bool ), cnnReuseMvs = 2 * 33;\n"
+                     "  auto cnnSaveReused = [&]( CnnReusedMvs &s ) {\n"
+                     "    const bool *fl = &g_isReusedUniMVsFilled[0][0][0][0]; const Mv *base = &g_reusedUniMVs[0][0][0][0][0][0];\n"
+                     "    s.idx.clear(); s.mvs.clear();\n"
+                     "    for( size_t i = 0; i < cnnReuseSlots; i++ ) if( fl[i] ) { s.idx.push_back( (uint32_t) i ); s.mvs.insert( s.mvs.end(), base + i * cnnReuseMvs, base + ( i + 1 ) * cnnReuseMvs ); }\n"
+                     "  };\n"
+                     "  auto cnnRestoreReused = [&]( const CnnReusedMvs &s ) {\n"
+                     "    bool *fl = &g_isReusedUniMVsFilled[0][0][0][0]; Mv *base = &g_reusedUniMVs[0][0][0][0][0][0];\n"
+                     "    ::memset( g_isReusedUniMVsFilled, 0, sizeof( g_isReusedUniMVsFilled ) );\n"
+                     "    for( size_t k = 0; k < s.idx.size(); k++ ) { fl[s.idx[k]] = true; std::copy( s.mvs.begin() + k * cnnReuseMvs, s.mvs.begin() + ( k + 1 ) * cnnReuseMvs, base + (size_t) s.idx[k] * cnnReuseMvs ); }\n"
+                     "  };\n"
                      "\n"
                      "  // for every CTU in the slice\n  for( size_t schedIdx = 0; schedIdx < sched.size(); schedIdx++ )\n  {\n"
                      "    const uint32_t ctuIdx   = sched[schedIdx].first;\n"
@@ -308,8 +327,9 @@ def n3_encslice_cpp(t):
                      "      cs.setPrevPLT( rowPLT[ctuYPosInCtus] );\n"
                      "      prevQP[0] = rowPrevQP[2 * ctuYPosInCtus]; prevQP[1] = rowPrevQP[2 * ctuYPosInCtus + 1];\n"
                      "      cnnInterSearch->restoreMeSeedLists( rowMe[ctuYPosInCtus] );\n"
+                     "      cnnRestoreReused( rowReused[ctuYPosInCtus] );\n"
                      "    }\n"
-                     "    if( cnnRowReset && ctuXPosInCtus == 0 ) { cnnInterSearch->resetAffineMVList(); cnnInterSearch->resetUniMvList(); }\n\n"
+                     "    if( cnnRowReset && ctuXPosInCtus == 0 ) { cnnInterSearch->resetAffineMVList(); cnnInterSearch->resetUniMvList(); ::memset( g_isReusedUniMVsFilled, 0, sizeof( g_isReusedUniMVsFilled ) ); }\n\n"
                      "    if( pCfg->getSwitchPOC() != pcPic->poc || -1 == pCfg->getDebugCTU() )\n", "row state restore")
     t = replace_once(t,
                      "  if (pCfg->getSwitchPOC() != pcPic->poc || ctuRsAddr >= pCfg->getDebugCTU())\n    m_pcCuEncoder->compressCtu( cs, ctuArea, ctuRsAddr, prevQP, currQP );\n",
@@ -332,6 +352,7 @@ def n3_encslice_cpp(t):
                      "      cs.storePrevPLT( rowPLT[ctuYPosInCtus] );\n"
                      "      rowPrevQP[2 * ctuYPosInCtus] = prevQP[0]; rowPrevQP[2 * ctuYPosInCtus + 1] = prevQP[1];\n"
                      "      cnnInterSearch->saveMeSeedLists( rowMe[ctuYPosInCtus] );\n"
+                     "      cnnSaveReused( rowReused[ctuYPosInCtus] );\n"
                      "    }\n"
                      "    // for last Ctu in the slice\n", "row state save")
     return t

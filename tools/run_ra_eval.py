@@ -8,6 +8,8 @@ one process per (leg, QP), several at a time.
                CTU 128 `:112`, MTT depth 3 `:119`, BIO / CIIP / Geo `:139-141`, LMCS `:145`, DMVR `:151`) when /root/reference is mounted.
                Checks: N1 -- bitstream(inject) == bitstream(anchor = no CU size enabled); N3 -- bitstream(MLTCNN_BATCH=1) ==
                bitstream(MLTCNN_BATCH=0) under WaveFrontSynchro=1; the batched stream decodes to the encoder's reconstruction.
+               --force-splits 2,1: the N3 pair again with every prediction "succeeding" with that split mode (MLTCNN_FORCE_SPLIT, test hook):
+               the decision-dependent encoder paths (setNewModeList with BT_H / QT) without a GPU -- how the global uni-MV reuse cache was found.
   --mode gpu   GPU box (the reference tree does not exist there): the same TOOL SET in tests/data/vtm_ra_tools.cfg (tools/make_ra_cfg.py),
                real decisions from seeded weights.  Per QP: anchor, serial (one mlt_predict per CU), MLTCNN_BATCH=0 and =1 under WPP
                (bit-identical), wall-clock / CPU time, time saving vs anchor, share of the encode inside the predictor (MLTCNN_STATS), batch-size
@@ -32,7 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 VTM = os.path.join(ROOT, "oracle", "_ref", "vtm")
 REF_CFG = "/root/reference/vtm-mlt-cpp/cfg/encoder_randomaccess_vtm.cfg"
 OWN_CFG = os.path.join(ROOT, "tests", "data", "vtm_ra_tools.cfg")
-ENV_KEYS = ("MLTCNN_FAULT_INJECT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS", "MLTCNN_DEVICES",
+ENV_KEYS = ("MLTCNN_FAULT_INJECT", "MLTCNN_FORCE_SPLIT", "MLTCNN_CALL_DUMP_FILE", "MLTCNN_SIZE_MASK", "MLTCNN_WEIGHTS_DIR", "MLTCNN_DEVICE", "MLTCNN_FLAGS", "MLTCNN_DEVICES",
             "MLTCNN_BATCH", "MLTCNN_BATCH_LOG", "MLTCNN_STATS")
 
 
@@ -102,6 +104,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=0)
     ap.add_argument("--cfg", default=None)
     ap.add_argument("--weight-seed", type=int, default=10)
+    ap.add_argument("--force-splits", default="", help="cpu mode: comma list of split modes forced through the test hook MLTCNN_FORCE_SPLIT, one N3 pair each")
     a = ap.parse_args()
     enc, dec = os.path.join(VTM, "EncoderApp"), os.path.join(VTM, "DecoderApp")
     assert os.path.exists(enc) and os.path.exists(dec), "patched EncoderApp not built (tools/build_vtm.sh, build container)"
@@ -130,6 +133,9 @@ def main():
             legs.append(("inject", q, {"MLTCNN_FAULT_INJECT": "1"}, []))
             legs.append(("wpp_serial", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_BATCH": "0"}, wpp))
             legs.append(("wpp_batch", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_BATCH": "1", "MLTCNN_BATCH_LOG": os.path.join(a.out, f"batch_q{q}.log")}, wpp))
+            for fs in [v for v in a.force_splits.split(",") if v]:
+                legs.append((f"wpp_serial_fs{fs}", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_FORCE_SPLIT": fs, "MLTCNN_BATCH": "0"}, wpp))
+                legs.append((f"wpp_batch_fs{fs}", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_FORCE_SPLIT": fs, "MLTCNN_BATCH": "1"}, wpp))
         else:
             w = {"MLTCNN_WEIGHTS_DIR": wdir, "MLTCNN_STATS": "1"}
             legs.append(("serial", q, dict(w), []))
@@ -180,6 +186,9 @@ def main():
             c["n1_inject_equals_anchor"] = logs[("inject", q)]["sha256"] == logs[("anchor", q)]["sha256"]
             c["inject_hello_count"] = logs[("inject", q)]["hello"]
         c["n3_batch_equals_serial"] = logs[("wpp_batch", q)]["sha256"] == logs[("wpp_serial", q)]["sha256"]
+        for fs in [v for v in a.force_splits.split(",") if v and a.mode == "cpu"]:
+            c[f"n3_batch_equals_serial_forced_split_{fs}"] = logs[(f"wpp_batch_fs{fs}", q)]["sha256"] == logs[(f"wpp_serial_fs{fs}", q)]["sha256"]
+            c[f"forced_split_{fs}_differs_from_full_rdo"] = logs[(f"wpp_serial_fs{fs}", q)]["sha256"] != logs[("wpp_serial", q)]["sha256"]
         # the batched stream decodes to the encoder's own reconstruction (SEI picture hashes verified when the cfg writes them)
         d = os.path.join(a.out, "wpp_batch")
         r = subprocess.run([dec, "-b", os.path.join(d, f"synth_q{q}.bin"), "-o", os.path.join(d, f"synth_q{q}_dec.yuv"), "-d", "10"], env=base_env(), capture_output=True, text=True)
@@ -188,6 +197,7 @@ def main():
         c["batch_histogram"] = eh.batch_histogram(open(bl).read()) if os.path.exists(bl) else {}
         summ["checks"][q] = c
         ok &= c["n3_batch_equals_serial"] and c["batch_decodes_to_recon"] and c.get("n1_inject_equals_anchor", True)
+        ok &= all(v for k, v in c.items() if k.startswith("n3_batch_equals_serial_forced_split_"))
     if a.mode == "gpu":
         for key, f in (("dump128", "calls128.bin"), ("allsizes", "calls_all.bin")):
             rep = check_dump_against_oracle(os.path.join(a.out, f), blobs)
