@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (C oracle over the whole batch = full-batch parity, torch port)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="CUs of the batch the C oracle evaluates (default: whole batch when the host has >= 64 cores)")
     ap.add_argument("--weight-seed", type=int, default=10, help="seed of the synthetic weight set (10 = the BASELINE workload; 13 / 24 land in the hi+lo-weights tier)")
+    ap.add_argument("--weights-blob", default="", help="an MLTW file instead of the seeded set (e.g. tools/train_synth_weights.py's trained family): another WORKLOAD, never the driver's line")
     ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags; 0 = the shipped configuration (calibrated arithmetic + flat-content guard + decision guard, what the encoder runs); "
                          "1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16, 0x20 = without the decision guard (measurement only)")
     ap.add_argument("--sustain-s", type=float, default=8.0,
@@ -151,7 +152,7 @@ def main():
     size, B = args.size, args.batch
     arch = pkg.synth.arch_for_size(size)
     # ---- weights: rank 0 builds the blob, everyone else receives it over RCCL (xGMI) ----
-    blob = pkg.weights.synthetic_blob(arch, args.weight_seed) if rank == 0 else None
+    blob = (open(args.weights_blob, "rb").read() if args.weights_blob else pkg.weights.synthetic_blob(arch, args.weight_seed)) if rank == 0 else None
     if dist is not None:
         pkg.shard.broadcast_blob(blob, dist, cdev)  # first collective also sets up the communicator: time the second
         torch.cuda.synchronize()
@@ -402,7 +403,7 @@ def main():
               "decisive_margin": 4e-5 if guarded else 2 * LOGIT_TOL,
               "oracle": "oracle/mlt_oracle.c (fp32 restatement pinned to the reference fixtures)"}
 
-    tier = int(arith["exact"])  # 0 fast, 1 exact, 2 hi+lo weights on fp16 activations in every stage, 3 in the stages of w2_stages only
+    tier = int(arith["exact"])  # 0 fast, 1 exact, 2 hi+lo weights on fp16 activations in every stage, 3 in the stages of w2_stages only, 4 exact stages, 5 exact-lite
     exact = tier == 1
     arith = m.arithmetic(size)
     def _unit(i):  # a stage with hi+lo weights in ONE of its two launch units is named by that unit
@@ -417,12 +418,12 @@ def main():
         "metric": f"CU-inferences/sec (batch {B}, {size}x{size})", "value": round(value, 1), "unit": "CU-inferences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else f"f16, weights hi+lo in {stages} (fp32 accumulate)" if tier == 3 else f"f16x2 pairs in {xstages}, f16 with weights hi+lo in {stages or 'no stage'} (fp32 accumulate)" if tier == 4 else "f16 (fp32 accumulate)", "data": "synthetic",
+        "dtype": "f16x2 (hi+lo pairs, fp32 accumulate)" if exact else "f16x2 pairs, cross terms in scaled fp8 (exact-lite, fp32 accumulate)" if tier == 5 else "f16 weights hi+lo x f16 activations (fp32 accumulate)" if tier == 2 else f"f16, weights hi+lo in {stages} (fp32 accumulate)" if tier == 3 else f"f16x2 pairs in {xstages}, f16 with weights hi+lo in {stages or 'no stage'} (fp32 accumulate)" if tier == 4 else "f16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if size == 128 else 2}]: batch {B} synthetic {size}x{size} CU patches per GPU, fp16 MFMA / fp32 accumulate, "
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
-                   "batch_per_gpu": B, "cu_size": size, "weights": f"synthetic seed {args.weight_seed} (no trained checkpoint is distributed)",
+                   "batch_per_gpu": B, "cu_size": size, "weights": (f"MLTW file {os.path.basename(args.weights_blob)}" if args.weights_blob else f"synthetic seed {args.weight_seed}") + " (no trained checkpoint is distributed)",
                    "parallelism": f"shard{world}",
-                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else "exact-lite (fp16 hi x hi + both cross terms in one scaled FP8 MFMA: 2 fp16-equivalent passes)" + (" + decision guard" if arith["decision_guard"] else "") if tier == 5 else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
                                   "w2_stages": int(arith["w2_stages"]), "w2_units": int(arith["w2_units"]), "x_stages": int(arith["x_stages"]), "x_units": int(arith["x_units"]), "weight_rounding": int(arith["rounding"]), "decision_guard_margin": arith["guard_margin"],
                                   "guard_reruns_total": arith["guard_reruns"], "guard_reruns_per_step": round(reruns_per_step, 2),

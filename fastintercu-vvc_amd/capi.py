@@ -22,6 +22,7 @@ FLAG_FAST_SMALL = 0x2  # 64/32/16 in fast arithmetic instead of exact
 FLAG_DECISION_GUARD = 0x4  # ABI <= 3 opt-in; since ABI 4 the decision guard is the default (accepted, no effect)
 FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (measurement only)
 FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
+FLAG_EXACT_LITE = 0x40  # round 5 (measurement): exact-configured sizes run the exact-lite arithmetic (FP8 cross terms)
 FLAG_NO_DECISION_GUARD = 0x20  # ABI 4: no exact re-evaluation of CUs with a near-tie on the decision head (measurement only)
 EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_calibrate", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",

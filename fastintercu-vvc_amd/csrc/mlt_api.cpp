@@ -60,6 +60,13 @@ struct SizeState {
                                // plane behind their activations), the other stages hi+lo weights (w2_mask = the complement) -- for weight sets whose
                                // ACTIVATION rounding, spread evenly over all 18 rounding sites, misses the contract by a few per cent
   unsigned x_units = 0;        // ... at launch-unit granularity (bit 2 s + u as in w2_units); x_mask = the stages with at least one exact unit
+  bool lite = false;           // round 5: the calibration found no fp16 tier within the contract but the exact-lite arithmetic is: `model` is the exact-lite
+                               // model (two activation planes, FP8 cross terms; mlt_model.h: xl), the flat guard is off (its error is 1/20 of the single
+                               // pass's), the decision guard -- if configured -- still re-evaluates near-ties with `model_exact`
+  bool cfg_flat_guard = false; // flat guard as configured (flags); flat_guard is what the loaded tier uses
+  float guard_margin = 3e-3f;  // decision guard's threshold for THIS size's tier: the context's (3 x tolerance, or as configured) -- except the exact-lite tier, whose
+                               // largest calibration error is ~ 1/6 of the tolerance: 3 x 1.7 x calib_max there (1.7: the tail probes' largest error over the
+                               // calibration set's), at least 1e-4, at most the context's
   bool want_exact = false;     // configured arithmetic (flags)
   bool flat_guard = false, margin_guard = false, calibrate = false;
   bool small_mix = false;      // 64 / 32 / 16 (round 4): configured exact, but the load-time calibration may keep the first stages -- the large maps, where the
@@ -78,6 +85,7 @@ struct SizeState {
   mlt::Model model;
   mlt::Model model_exact;      // fast sizes: exact-arithmetic copy the guards re-evaluate flagged CUs with
   mlt::Model model_w2;         // hi+lo-weights copy on the fast tiling (MLT_MODEL_W2); built only when the single-pass calibration fails
+  mlt::Model model_xl;         // exact-lite copy (MLT_MODEL_XLITE): exists only while the calibration prices it; the tier's model moves into `model`
   bool guards() const { return !exact && (flat_guard || margin_guard) && model_exact.on_device; }
 };
 
@@ -133,6 +141,7 @@ struct mlt_ctx {
   bool own_stream = false;
   SizeState sz[4];
   float guard_margin = 3e-3f;  // decision guard: 3 x tolerance unless configured (mlt_init)
+  bool guard_margin_configured = false;  // mlt_config.guard_margin > 0: used as is for every tier
   int max_batch = 4096, chunk = 4096;  // CUs per pass; MLT_CHUNK overrides (workspace ~1.5 MiB per CU at S = 128)
   char *ws = nullptr;
   size_t ws_bytes = 0;
@@ -152,6 +161,7 @@ struct mlt_ctx {
   size_t stage_bytes = 0;
   // parity guards: selection buffers for two in-flight batches, gather staging for the flagged CUs
   float tolerance = 1e-3f;
+  bool xlite = false;  // MLT_FLAG_EXACT_LITE: sizes configured exact run the exact-lite arithmetic (FP8 cross terms, mlt_model.h: xl)
   char *guard_dev = nullptr;
   size_t guard_slot_bytes = 0;
   int guard_cap_n = 0, guard_cap_nl = 0;
@@ -311,6 +321,10 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.hin_l = ilog2(hin); a.hout_l = ilog2(hout);
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   a.lo8_scale = 0x01010101 * ((127 - pc.lo8_exp) & 0xFF);
+  a.xl_sa0 = 0x01010101 * ((127 - pc.xl_ewl) & 0xFF); a.xl_sa1 = 0x01010101 * ((127 - pc.xl_ewh) & 0xFF); a.xl_sb1 = 0x01010101 * (127 - 12);  // (12 = MLT_XL_LO_EXP, mlt_kernels.hip)
+  { static const int kill = [] { const char *e = tuning_env("MLT_XL_KILL"); return e ? std::atoi(e) : 0; }();  // bring-up: E8M0 byte 0 = 2^-127 silences a K block
+    static const int only = [] { const char *e = tuning_env("MLT_XL_KILL_LAYER"); return e ? std::atoi(e) : -1; }();  // cin * 1000 + cout
+    if (only < 0 || only == pc.cin * 1000 + pc.cout) { if (kill & 1) a.xl_sa0 = 0; if (kill & 2) a.xl_sb1 = 0; } }
   // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
   // Small batches (the encoder's one-CU-per-call use): the throughput tiling would put a whole layer on 1-4 workgroups
   // that stream all its weights through their LDS one after the other.  The latency variants cut the couts into 32-channel
@@ -323,8 +337,8 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const bool lat = !(pc.exact && no_exact_lat) && pc.lat && hout >= 8 && (pc.w2 ? pc.stride == 1 : (long)n * hout * hout <= lat_px);
   const int dma = (pc.exact || pc.w2 || lat) ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
   const int MT = lat ? 128 : dma == 2 ? pc.mt_dma : pc.mt;
-  const int nsplit = pc.exact ? 2 : pc.w2 ? 4 : 1;  // (mlt_launch_conv)
-  const int act_planes = nsplit == 2 ? 2 : 1;
+  const int nsplit = pc.xl ? 6 : pc.exact ? 2 : pc.w2 ? 4 : 1;  // (mlt_launch_conv; 6 = exact-lite: the exact arithmetic's geometry, FP8 cross terms)
+  const int act_planes = (nsplit == 2 || nsplit == 6) ? 2 : 1;
   int tw = hout < 32 ? hout : 32;
   int th = MT / tw < hout ? MT / tw : hout;
   int spw = MT / (tw * th);
@@ -340,7 +354,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   // LDS budget of the patch planes: 64 KiB -- or, for the exact arithmetic (two planes), what the two-deep weight ring of the tiling leaves of the
   // 160 KiB (round 4: the 128 -> 256 stride-2 layer on 8 x 8 maps needs 96 KiB for TWO samples per tile; with one, half of the tile's waves idled)
   size_t patch_budget = 64 * 1024;
-  if (nsplit == 2) {
+  if (nsplit == 2 || nsplit == 6) {
     const int tt = pc.taps + (pc.has_sc ? 1 : 0), nbuf = tt / pc.gt > 1 ? 2 : 1;
     const size_t ring = (size_t)nbuf * 2 * pc.gt * (pc.kc / 16) * (pc.ct / 32) * 1024;
     static const bool big = tuning_env("MLT_EXACT_PATCH_64K") == nullptr;
@@ -755,7 +769,7 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
     // one CU (mlt_predict's captured graph): the selection is a tail of the heads kernel -- no guard_select launch, no memset of the
     // statistic (the tail clears it for the next call; it is only consumed when the first kernel is the one that produces it: aligned planes,
     // S >= 64 -- else flat_stat_kernel overwrites it), no separate copy of the count (the caller's result copy carries it)
-    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / 8, (S * S / 4) / 2, st.margin_guard ? ctx->guard_margin : 0.f};
+    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / 8, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f};
     return run_main(ctx, st, 1, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg, st.flat_guard ? g.d_flat : nullptr, &tail, true);
   }
   if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
@@ -769,7 +783,7 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   sa.head_off = off; sa.head_classes = st.model.heads[st.head_index].classes;
   sa.flat_thr = (S * S / 4) / 8;  // >= 1/8 of the quads exactly flat (constant / exactly linear in both planes)
   sa.near_thr = (S * S / 4) / 2;  // or >= 1/2 of them near-flat (mlt_kernels.h: MLT_FLAT_RANGE)
-  sa.margin = st.margin_guard ? ctx->guard_margin : 0.f;
+  sa.margin = st.margin_guard ? st.guard_margin : 0.f;
   if ((rc = L.prof_begin("guard_select", 0.0, 0.0, e0, e1))) return rc;
   HIP_TRY(ctx, mlt_launch_guard_select(sa, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
@@ -959,7 +973,7 @@ struct CalibSession {
     (void)hipStreamSynchronize(ctx->stream);
     release_ws(ctx);
   }
-  int run(std::vector<float> &out, bool exact, unsigned mask, unsigned xmask = 0) {
+  int run(std::vector<float> &out, bool exact, unsigned mask, unsigned xmask = 0, mlt::Model *whole = nullptr) {
     const int S = st.size, nl = st.model.n_logits;
     const long cs = (long)S * S;
     const bool prof = ctx->profile;
@@ -967,7 +981,8 @@ struct CalibSession {
     int rc = MLT_OK;
     for (int i0 = 0; i0 < n && rc == MLT_OK; i0 += kSub) {
       const int c = n - i0 < kSub ? n - i0 : kSub;
-      rc = exact ? run_network(ctx, st, st.model_exact, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl)
+      rc = whole ? run_network(ctx, st, *whole, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl)
+         : exact ? run_network(ctx, st, st.model_exact, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl)
                  : run_network(ctx, st, st.model, c, d_org + (size_t)i0 * cs, S, cs, d_pred + (size_t)i0 * cs, S, cs, d_poc + i0, d_qp + i0, d_split, d_lg + (size_t)i0 * nl,
                                nullptr, mask ? &st.model_w2 : nullptr, mask, nullptr, false, xmask ? &st.model_exact : nullptr, xmask);
     }
@@ -1023,8 +1038,8 @@ struct CalibSession {
     for (int i = 0; i < n; ++i) { n_used += use[(size_t)i]; if (i >= n_syn) n_caller_used += use[(size_t)i]; }
     return run(le, true, 0);
   }
-  int price(unsigned mask, unsigned xmask = 0) {
-    int rc = run(lf, false, mask, xmask);
+  int price(unsigned mask, unsigned xmask = 0, mlt::Model *whole = nullptr) {
+    int rc = run(lf, false, mask, xmask, whole);
     if (rc) return rc;
     const int nl = st.model.n_logits;
     double mx = 0.0, s2_all = 0.0;
@@ -1100,6 +1115,19 @@ struct DevicePricer : mlt::TierPricer {
     out.rms = st.calib_rms; out.max = st.calib_max; out.tail = cal.tail_ratio;
     return MLT_OK;
   }
+  int price_lite(mlt::TierPrice &out) override {
+    std::string err;
+    int rc;
+    if (!st.model_xl.on_device) {
+      mlt::Model mx;
+      if (!mlt::build_model(blob, bytes, mlt::MLT_MODEL_XLITE, size, mx, err)) { ctx->err = "weights (exact-lite copy): " + err; return MLT_ERR_WEIGHTS; }
+      st.model_xl = std::move(mx);
+      if ((rc = upload_model(ctx, st.model_xl))) return rc;
+    }
+    if ((rc = cal.price(0, 0, &st.model_xl))) return rc;
+    out.rms = st.calib_rms; out.max = st.calib_max; out.tail = cal.tail_ratio;
+    return MLT_OK;
+  }
 };
 
 int env_int(const char *name) {  // tuning switch holding a number (MLT_TUNING=1 only); -1: not set
@@ -1112,8 +1140,8 @@ void unload_size(mlt_ctx *ctx, int si) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   drop_graphs(ctx, si);
-  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
-  st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model();
+  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
+  st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model(); st.model_xl = mlt::Model();
   st.loaded = false;
 }
 
@@ -1128,7 +1156,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   mlt::Model m;
   static const bool no_small_mix = tuning_env("MLT_NO_SMALL_MIX") != nullptr;
   const bool small_mix = st.small_mix && !no_small_mix;   // (then: fast copy = `model`, exact copy = `model_exact`, the calibration picks the stages)
-  if (!mlt::build_model(blob, bytes, (st.want_exact && !small_mix) ? mlt::MLT_MODEL_EXACT : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
+  if (!mlt::build_model(blob, bytes, (st.want_exact && !small_mix) ? (ctx->xlite ? mlt::MLT_MODEL_XLITE : mlt::MLT_MODEL_EXACT) : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
   if (st.head_index < 0 || st.head_index >= m.n_heads) { ctx->err = "head_index out of range"; return MLT_ERR_ARG; }
   // a reload replaces device buffers that captured graphs and in-flight work point to
@@ -1136,18 +1164,20 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   drop_graphs(ctx, si);
   // (models own device buffers: whatever the state held -- loaded or left over from a failed load -- is released first, and every
   // error path below releases what it uploaded, so a failed reload leaves the size cleanly unloaded instead of leaking)
-  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
+  free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
   st.loaded = false;
   st.exact = st.want_exact && !small_mix;
+  st.lite = false; st.flat_guard = st.cfg_flat_guard; st.guard_margin = ctx->guard_margin;
   st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.calib_cus = st.calib_caller_cus = 0;
   st.model = std::move(m);
   st.model_exact = mlt::Model();
   st.model_w2 = mlt::Model();
+  st.model_xl = mlt::Model();
   auto fail = [&](int rc) {
-    free_model(st.model); free_model(st.model_exact); free_model(st.model_w2);
-    st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model();
+    free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
+    st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model(); st.model_xl = mlt::Model();
     return rc;
   };
   int rc = upload_model(ctx, st.model);
@@ -1175,19 +1205,30 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
       force.w2_units = env_int("MLT_W2_UNITS"); force.small_prefix = env_int("MLT_SMALL_PREFIX");
       force.no_roundings = tuning_env("MLT_NO_ROUNDINGS") != nullptr; force.no_w2 = tuning_env("MLT_NO_W2") != nullptr;
       force.no_xmix = tuning_env("MLT_NO_XMIX") != nullptr; force.no_w2_units = tuning_env("MLT_NO_W2_UNITS") != nullptr;
-      force.no_x_units = tuning_env("MLT_NO_X_UNITS") != nullptr;
+      force.no_x_units = tuning_env("MLT_NO_X_UNITS") != nullptr; force.no_lite = tuning_env("MLT_NO_LITE") != nullptr;
       mlt::TierChoice ch;
       rc = small_mix ? mlt::search_tier_small(pricer, rules, force, st.model.n_stages, ch) : mlt::search_tier_128(pricer, rules, force, mlt::MLT_N_ROUNDINGS, ch);
       if (rc) return fail(rc);
       st.calib_cus = cal.n_used; st.calib_caller_cus = cal.n_caller_used;
       st.calib_rms = ch.price.rms; st.calib_max = ch.price.max;
-      if (ch.exact) {  // run it exact
+      if (ch.lite) {  // the exact-lite arithmetic everywhere: its model becomes `model`; the exact copy stays for the decision guard's near-ties
         free_model(st.model_w2); st.model_w2 = mlt::Model();
+        free_model(st.model);
+        st.model = std::move(st.model_xl);
+        st.model_xl = mlt::Model();
+        st.lite = true;
+        st.flat_guard = false;
+        if (!ctx->guard_margin_configured) st.guard_margin = std::min(ctx->guard_margin, std::max(1e-4f, 3.f * 1.7f * st.calib_max));
+        if (!st.margin_guard) { free_model(st.model_exact); st.model_exact = mlt::Model(); }
+      } else if (ch.exact) {  // run it exact
+        free_model(st.model_w2); st.model_w2 = mlt::Model();
+        free_model(st.model_xl); st.model_xl = mlt::Model();
         free_model(st.model);
         st.model = std::move(st.model_exact);
         st.model_exact = mlt::Model();
         st.exact = true;
       } else {
+        free_model(st.model_xl); st.model_xl = mlt::Model();
         st.w2 = ch.w2;
         st.w2_units = ch.w2_units; st.x_units = ch.x_units;
         st.w2_mask = mlt::stages_of_units(ch.w2_units); st.x_mask = mlt::stages_of_units(ch.x_units);
@@ -1211,7 +1252,7 @@ int load_all(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
     if (rc) ctx->err = "device " + std::to_string(p->device) + ": " + p->err;
     else {
       const SizeState &a = ctx->sz[si], &b = p->sz[si];
-      if (a.exact != b.exact || a.w2 != b.w2 || a.w2_units != b.w2_units || a.x_units != b.x_units || a.model.rounding != b.model.rounding) {
+      if (a.exact != b.exact || a.lite != b.lite || a.w2 != b.w2 || a.w2_units != b.w2_units || a.x_units != b.x_units || a.model.rounding != b.model.rounding) {
         ctx->err = "device " + std::to_string(p->device) + " calibrated to a different arithmetic than device " + std::to_string(ctx->device);
         rc = MLT_ERR_WEIGHTS;
       }
@@ -1274,6 +1315,7 @@ int mlt_tier_search_run(int kind, int n, float tolerance, float max_frac, const 
       out.rms = o[0]; out.max = o[1]; out.tail = o[2];
       return rc;
     }
+    int price_lite(mlt::TierPrice &out) override { return price(~0u, ~0u, 0, out); }
   } pricer;
   pricer.cb = price_cb; pricer.user = user;
   mlt::TierRules rules;
@@ -1282,12 +1324,12 @@ int mlt_tier_search_run(int kind, int n, float tolerance, float max_frac, const 
   mlt::TierForce f;
   if (force) {
     f.rounding = force[0]; f.w2_mask = force[1]; f.x_mask = force[2]; f.w2_units = force[3]; f.small_prefix = force[4];
-    f.no_roundings = force[5] != 0; f.no_w2 = force[6] != 0; f.no_xmix = force[7] != 0; f.no_w2_units = force[8] != 0; f.no_x_units = force[9] != 0;
+    f.no_roundings = force[5] != 0; f.no_w2 = force[6] != 0; f.no_xmix = force[7] != 0; f.no_w2_units = force[8] != 0; f.no_x_units = force[9] != 0; f.no_lite = force[10] != 0;
   }
   mlt::TierChoice ch;
   const int rc = kind == 0 ? mlt::search_tier_128(pricer, rules, f, n, ch) : mlt::search_tier_small(pricer, rules, f, n, ch);
   result[0] = ch.exact ? 1 : 0; result[1] = ch.w2 ? 1 : 0; result[2] = (int)ch.w2_units; result[3] = (int)ch.x_units; result[4] = ch.rounding; result[5] = ch.priced;
-  result[6] = result[7] = 0;
+  result[6] = ch.lite ? 1 : 0; result[7] = 0;
   figures[0] = ch.price.rms; figures[1] = ch.price.max; figures[2] = ch.price.tail;
   return rc;
 }
@@ -1299,13 +1341,13 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   SizeState *st;
   int rc = check_size(ctx, size, &st);
   if (rc) return rc;
-  out->exact = st->exact ? 1 : st->x_units ? 4 : st->w2 ? (st->w2_units != 0xFFu ? 3 : 2) : 0;
+  out->exact = st->exact ? 1 : st->lite ? 5 : st->x_units ? 4 : st->w2 ? (st->w2_units != 0xFFu ? 3 : 2) : 0;
   out->w2_stages = st->w2 ? (int32_t)st->w2_mask : 0;
   out->x_stages = st->exact ? 0 : (int32_t)st->x_mask;
   out->w2_units = st->w2 ? (int32_t)st->w2_units : 0;
   out->x_units = st->exact ? 0 : (int32_t)st->x_units;
   out->rounding = st->model.rounding;
-  out->guard_margin = (!st->exact && st->margin_guard) ? ctx->guard_margin : 0.f;
+  out->guard_margin = (!st->exact && st->margin_guard) ? st->guard_margin : 0.f;
   out->calibrated = st->calibrated ? 1 : 0;
   out->calib_rms = st->calib_rms; out->calib_max = st->calib_max;
   out->flat_guard = (!st->exact && st->flat_guard) ? 1 : 0;
@@ -1332,10 +1374,12 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
   ctx->device = device;
   ctx->max_batch = cfg->max_batch > 0 ? cfg->max_batch : 4096;
   if (cfg->tolerance > 0.f) ctx->tolerance = cfg->tolerance;
+  ctx->xlite = (cfg->flags & MLT_FLAG_EXACT_LITE) != 0;
   // decision guard: two logits that are each within `tolerance` of the reference change their difference by at most 2 x tolerance.  The
   // admission of the fast arithmetic is calibrated, not proven (the tail probes put single logits at up to ~1.1 x tolerance), so the
   // default threshold is 3 x tolerance: everything below it is re-evaluated exactly (the extra re-runs are a fraction of a per cent)
   ctx->guard_margin = cfg->guard_margin > 0.f ? cfg->guard_margin : 3.f * ctx->tolerance;
+  ctx->guard_margin_configured = cfg->guard_margin > 0.f;
   if (const char *e = tuning_env("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
   if (const char *e = tuning_env("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
   if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
@@ -1374,7 +1418,7 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
     // unless MLT_FLAG_FAST_SMALL.  See DESIGN.md "Numerics".
     st.want_exact = st.exact = sizes[i] == 128 ? (cfg->flags & MLT_FLAG_EXACT_128) != 0 : (cfg->flags & MLT_FLAG_FAST_SMALL) == 0;
     st.margin_guard = (cfg->flags & MLT_FLAG_NO_DECISION_GUARD) == 0;  // ABI 4: on by default (MLT_FLAG_DECISION_GUARD is accepted and has no effect)
-    st.flat_guard = (cfg->flags & MLT_FLAG_NO_FLAT_GUARD) == 0;
+    st.flat_guard = st.cfg_flat_guard = (cfg->flags & MLT_FLAG_NO_FLAT_GUARD) == 0;
     // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
     st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
     st.small_mix = sizes[i] != 128 && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
@@ -1441,7 +1485,7 @@ void mlt_shutdown(mlt_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->prof)
     for (auto &ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  for (int i = 0; i < 4; ++i) { free_model(ctx->sz[i].model); free_model(ctx->sz[i].model_exact); free_model(ctx->sz[i].model_w2); }
+  for (int i = 0; i < 4; ++i) { free_model(ctx->sz[i].model); free_model(ctx->sz[i].model_exact); free_model(ctx->sz[i].model_w2); free_model(ctx->sz[i].model_xl); }
   for (SingleCu &sg : ctx->single) {
     if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
     if (sg.graph) (void)hipGraphDestroy(sg.graph);

@@ -49,6 +49,8 @@ struct ConvArgs {
   // exact mode (NSPLIT == 2): byte offsets from each hi plane to its lo plane
   size_t x_lo_off, y_lo_off, res_lo_off, ysc_lo_off, w_lo_off;  // exact arithmetic: byte offsets hi plane -> lo plane (x_lo_off / res_lo_off == 0: that input has no lo plane, its lo part is zero)
   int lo8_scale;               // NSPLIT == 5 (hi fp16 + FP8 lo plane): E8M0 scale byte of the lo plane, replicated (mlt_model.h: lo8_exp)
+  int xl_sa0, xl_sa1, xl_sb1;  // NSPLIT == 6 (exact-lite): replicated E8M0 bytes -- A operand lanes 0-31 (e4m3 Wl: 127 - xl_ewl) / lanes 32-63 (e4m3 Wh: 127 - xl_ewh),
+                               // B operand lanes 32-63 (e4m3 Xl: 127 - MLT_XL_LO_EXP); B lanes 0-31 (e4m3 Xh) are unscaled
 };
 
 struct ConvCfg { int kc, ct, mt, gt, dma, mt_dma, lat, gt_w2; };  // gt_w2 (exact packing only): taps per weight step of the hi+lo-WEIGHTS tier (NSPLIT = 3)  // cin chunk, couts / pixels per workgroup, taps per weight step, LDS-DMA staging variant (0 none, 1 resident, 2 ring) and its pixels per workgroup

@@ -192,6 +192,31 @@ __device__ __forceinline__ float16v mfma_lo8(const half8 &a_lo, const half8 &a_h
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, 0x7F7F7F7F);  // fp8 x fp8; A scaled by 2^-lo8_exp, B by 1
 }
 
+// ---- exact-lite (NSPLIT == 6, round 5): both cross terms of the (hi, lo) product in ONE scaled FP8 MFMA ----
+// lo parts of 8 fp16 activations (signed, |lo| <= 2^-11 |x|) * 2^12 -> 8 e4m3 bytes; clamped so that neither the fp16 product nor the e4m3
+// conversion overflows (activations beyond ~220 lose part of their lo term; the calibration measures the outcome like any other tier's)
+#define MLT_XL_LO_EXP 12
+__device__ __forceinline__ void cvt_frag_fp8_lo(const half8 &v, uint32_t &d0, uint32_t &d1) {
+  const half2v top = {(_Float16)0.109375, (_Float16)0.109375}, mul = {(_Float16)4096, (_Float16)4096};  // 448 / 4096
+  const half2v *h = (const half2v *)&v;
+  short2v r = {0, 0}, q = {0, 0};
+  auto prep = [&](half2v x) { return __builtin_elementwise_max(__builtin_elementwise_min(x, top), -top) * mul; };
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, prep(h[0]), 1.0f, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, prep(h[1]), 1.0f, true);
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, prep(h[2]), 1.0f, false);
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, prep(h[3]), 1.0f, true);
+  d0 = *(uint32_t *)&r;
+  d1 = *(uint32_t *)&q;
+}
+// A = [e4m3 Wl | e4m3 Wh] (lanes 0-31 | 32-63), B = [e4m3 Xh ; e4m3 Xl]; scale_a / scale_b: this LANE's E8M0 byte (replicated) for its 32 K elements
+__device__ __forceinline__ float16v mfma_xl8(const half8 &a_lo, const half8 &a_hi, const half8 &b_lo, const half8 &b_hi, const float16v &c, int scale_a, int scale_b) {
+  int8v a, b;
+  const uint32_t *pl = (const uint32_t *)&a_lo, *ph = (const uint32_t *)&a_hi, *ql = (const uint32_t *)&b_lo, *qh = (const uint32_t *)&b_hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a[e] = (int)pl[e]; a[4 + e] = (int)ph[e]; b[e] = (int)ql[e]; b[4 + e] = (int)qh[e]; }
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+}
+
 // ---- 16-byte epilogue I/O -------------------------------------------------------------------------------------
 // After a 32x32 MFMA lane l = (p, h) holds, per register quad q, output channels 8q+4h .. 8q+4h+3 of pixel p, so
 // lanes p and p+32 own the two 8-byte halves of one 16-byte span.  v_permlane32_swap exchanges the upper half-wave
@@ -271,10 +296,10 @@ static hipError_t launch_conv_t(const ConvArgs &a, int grid_x, int extra_lds, hi
   constexpr int CBT = WCB * WAVES_C;
   constexpr int TT = TAPS + (SC ? 1 : 0);
   constexpr int NBUF = (TT / GT) > 1 ? RB : 1;
-  const int patch_lds = (DMA ? 2 : (NSPLIT == 2 ? 2 : 1)) * a.patch_bytes;
+  const int patch_lds = (DMA ? 2 : ((NSPLIT == 2 || NSPLIT == 6) ? 2 : 1)) * a.patch_bytes;
   // (NSPLIT == 5: + the FP8 lo plane of every ring step and the e4m3 copy of the patch, 80 bytes per pixel of the fp16 patch's KC * 2 + 16)
   const int patch8 = NSPLIT == 5 ? ((a.patch_bytes / (KC * 2 + 16) + 1) * (KC + 16) + 1023) / 1024 * 1024 : 0;
-  const int lds = patch_lds + NBUF * ((NSPLIT == 2 || NSPLIT == 3 ? 2 : 1) * GT * (KC / 16) * CBT * 1024 + (NSPLIT == 5 ? GT * CBT * 2048 : 0)) + patch8 + extra_lds;
+  const int lds = patch_lds + NBUF * ((NSPLIT == 2 || NSPLIT == 3 || NSPLIT == 6 ? 2 : 1) * GT * (KC / 16) * CBT * 1024 + (NSPLIT == 5 ? GT * CBT * 2048 : 0)) + patch8 + extra_lds;
   static DeviceOnce once;
   if (hipError_t e = ensure_big_lds(kern, once); e != hipSuccess) return e;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -518,6 +543,7 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out) {
   if (cin == CIN && cout == COUT && stride == STRIDE) {                                                                             \
     if (!exact) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCF, 1, WCB, WPB, WC, WPF, GTF, RBF, UNF, MWF, false>(a, grid_x, extra_lds, st); \
     if (nsplit == 3) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 3, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st); \
+    if (nsplit == 6) return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 6, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st); \
     return launch_conv_t<CIN, COUT, STRIDE, 9, SCF, KCE, 2, WCB, WPB, WC, WPE, GTE, RBE, UNE, 1, false>(a, grid_x, extra_lds, st);          \
   }
 #define CONV_CASE(CIN, COUT, STRIDE, SCF, KCF, KCE, WCB, WPB, WC, WP, GTF, GTE, RBF, RBE, UNF, UNE, MWF) \
@@ -546,7 +572,7 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
   }
   const bool exact = nsplit >= 2;
   const bool dma = variant == MLT_CONV_DMA;
-  if (variant == MLT_CONV_CENTRE && nsplit == 3) return hipErrorInvalidValue;  // (1x1 maps: small-CU models only, which do not use this tier)
+  if (variant == MLT_CONV_CENTRE && (nsplit == 3 || nsplit == 6)) return hipErrorInvalidValue;  // (1x1 maps: small-CU models only, which do not use this tier)
   if (variant == MLT_CONV_CENTRE) {  // stride-1 layers of the small-CU models on 1x1 maps: centre tap only (TAPS = 1), 128 samples per tile
     if (cin == 128 && cout == 128 && stride == 1)
       return exact ? launch_conv_t<128, 128, 1, 1, false, 32, 2, CFG_BIG_WCB, 1, CFG_BIG_WC, CFG_BIG_WP_EXACT, 1, 1, 2, 1, false>(a, grid_x, extra_lds, st)
@@ -560,6 +586,14 @@ hipError_t mlt_launch_conv(int cin, int cout, int stride, int nsplit, int varian
     return hipErrorInvalidValue;
   }
 #if CFG_LAT
+  if (variant == MLT_CONV_LATENCY && nsplit == 6) {  // exact-lite, small launches: the geometry of the exact arithmetic's latency variants (same per-accumulator order as the large tiles)
+    if (cin == 64 && cout == 64 && stride == 1) return launch_conv_t<64, 64, 1, 9, false, 32, 6, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 2>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 128 && stride == 1) return launch_conv_t<128, 128, 1, 9, false, 32, 6, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 256 && cout == 256 && stride == 1) return launch_conv_t<256, 256, 1, 9, false, 32, 6, 1, 1, 1, 4, CFG_GTE_S1, 2, 4, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 64 && cout == 128 && stride == 2) return launch_conv_t<64, 128, 2, 9, true, 32, 6, 1, 1, 1, 4, CFG_GTE_S2, 2, 5, 1, false, 4>(a, grid_x, extra_lds, st);
+    if (cin == 128 && cout == 256 && stride == 2) return launch_conv_t<128, 256, 2, 9, true, 32, 6, 1, 1, 1, 4, CFG_GTE_S2, 2, 5, 1, false, 4>(a, grid_x, extra_lds, st);
+    return hipErrorInvalidValue;
+  }
   if (variant == MLT_CONV_LATENCY && nsplit == 2) {
     // Exact arithmetic, small launches (round 4: the guards' re-runs of a few flagged CUs, one-CU calls of the exact / exact-stage tiers, small
     // batches of the small models): the same 32-cout x 128-pixel tiles on the exact packing (4x the workgroups, a quarter of the weight

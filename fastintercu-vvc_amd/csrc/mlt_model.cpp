@@ -193,6 +193,34 @@ static void pack_conv(PackedConv &pc, const float *w, const std::vector<double> 
       if (w_sc) put(at(taps), (double)w_sc[(size_t)co * cin + ci] * scale_sc[co], err_sc);
     }
   }
+  if (pc.xl) {
+    // exact-lite: the lo plane becomes the FP8 A operand of the cross-term MFMA (mlt_model.h).  Power-of-two scales put the largest |Wl| / |Wh|
+    // into [112, 224] -- inside e4m3's range (max 448) with headroom; the MFMA's E8M0 block scales undo them.
+    const size_t np = pc.plane_halves;
+    std::vector<uint16_t> lo16(pc.w.begin() + np, pc.w.end());
+    double lomax = 1e-30, himax = 1e-30;
+    for (size_t k = 0; k < np; ++k) { lomax = std::max(lomax, std::fabs((double)f16_to_f32(lo16[k]))); himax = std::max(himax, std::fabs((double)f16_to_f32(pc.w[k]))); }
+    pc.xl_ewl = std::min(60, (int)std::floor(std::log2(224.0 / lomax)));
+    pc.xl_ewh = std::min(60, (int)std::floor(std::log2(224.0 / himax)));
+    const double ml = std::ldexp(1.0, pc.xl_ewl), mh = std::ldexp(1.0, pc.xl_ewh);
+    uint8_t *lo = (uint8_t *)(pc.w.data() + np);
+    std::memset(lo, 0, np * 2);
+    for (int co = 0; co < cout; ++co) {
+      const int ctile = co / CT, cbt = (co % CT) / 32, r = co % 32;
+      for (int ci = 0; ci < cin; ++ci) {
+        const int chunk = ci / KC, kk = ci % KC, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
+        for (int t = 0; t < tt; ++t) {
+          const size_t hidx = ((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + ks) * CBT + cbt) * 512 + (size_t)(hh * 32 + r) * 8 + j;  // this weight in the fp16 planes
+          // FP8 operand: 16-byte half g of lane (kk >> 4) * 32 + r sits in k-step slot g of the lo plane; half 0 = Wl (K block 0: bytes 0-15 of BOTH
+          // lane halves, scaled by lanes 0-31), half 1 = Wh (K block 1) -- scripts/probes/f8_mfma_scale_probe2.hip
+          const size_t blk0 = ((((size_t)(ctile * NCHUNK + chunk) * tt + t) * KS + 0) * CBT + cbt) * 1024, blk1 = blk0 + (size_t)CBT * 1024;
+          const size_t lane16 = (size_t)((kk >> 4) * 32 + r) * 16 + (kk & 15);
+          lo[blk0 + lane16] = f32_to_e4m3((float)((double)f16_to_f32(lo16[hidx]) * ml));
+          lo[blk1 + lane16] = f32_to_e4m3((float)((double)f16_to_f32(pc.w[hidx]) * mh));
+        }
+      }
+    }
+  }
   if (pc.lo8) {
     double lomax = 1e-30;
     for (double v : lo8v) lomax = std::max(lomax, std::fabs(v));
@@ -339,7 +367,8 @@ static void pack_stem_b(PackedConv &pc, const float *ws, const float *w1, const 
 }
 
 bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, std::string &err, int rounding) {
-  const bool exact = mode == MLT_MODEL_EXACT, w2 = mode == MLT_MODEL_W2;
+  const bool xlite = mode == MLT_MODEL_XLITE;   // exact-lite: the exact packing (two planes, exact tiling) with FP8 lo planes in the 3x3 convs (mlt_model.h)
+  const bool exact = mode == MLT_MODEL_EXACT || xlite, w2 = mode == MLT_MODEL_W2;
   if (bytes < sizeof(BlobHead)) { err = "blob too small"; return false; }
   const BlobHead *h = (const BlobHead *)blob;
   if (std::memcmp(h->magic, "MLTW", 4) != 0 || h->version != 1 || h->arch > 1) { err = "not an MLTW v1 blob"; return false; }
@@ -356,6 +385,7 @@ bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, s
   m = Model();
   m.arch = (int)h->arch;
   m.exact = exact;
+  m.xl = xlite;
   m.w2 = w2;
   m.rounding = (exact || w2) ? 0 : rounding;
   static const int planes_ctu[4] = {32, 64, 128, 256}, planes_cu[5] = {32, 64, 96, 128, 256};  // arch:243-256 / cu arch:63-79
@@ -428,6 +458,7 @@ bool build_model(const void *blob, size_t bytes, int mode, int size, Model &m, s
           fold_scale(b, nm, c, scale_sc, pc.bias_sc, err);
           if (!err.empty()) return false;
         }
+        pc.xl = xlite && pc.taps == 9 && pc.kc == 32;   // (the centre-tap forms of the small models' 1x1 maps and the composed first layer stay exact)
         pack_conv(pc, w, scale, wsc, scale_sc, m.rounding);
         return true;
       };

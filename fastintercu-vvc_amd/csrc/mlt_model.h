@@ -27,6 +27,11 @@ struct PackedConv {
   int lo8_exp = 0;             // the MFMA's block scale undoes it (E8M0 byte 127 - lo8_exp)
   bool w2 = false;             // hi+lo-WEIGHTS tier on the FAST tiling (kc / ct / gt of the single-pass kernels): two planes like `exact`, read by the
                                // W2 forms of the fused kernels (chain_kernel, stem_block_kernel, block32_kernel) and by conv_mfma_kernel<NSPLIT = 3>
+  bool xl = false;             // exact-lite (round 5, MLT_MODEL_XLITE; conv_mfma_kernel NSPLIT == 6): the exact packing with the lo plane replaced, byte for byte, by
+                               // the FP8 A operand of the cross-term MFMA -- per (cout tile, chunk, tap, k-step slot g, 32-cout block) 1 KiB = [lane 64][16 bytes]:
+                               // slot 0, lane 32 h + r = e4m3(Wl[cout r][cin 16 h + b] * 2^xl_ewl), slot 1 = e4m3(Wh[...] * 2^xl_ewh), b = 0..15 (the hardware's
+                               // K block 0 is bytes 0-15 of both lane halves, block 1 bytes 16-31: scripts/probes/f8_mfma_scale_probe2.hip)
+  int xl_ewl = 0, xl_ewh = 0;
   size_t plane_halves = 0;     // halves per plane
   float acc_scale = 1.f;       // stored weights = folded weights * 2^s; kernels multiply accumulators by 2^-s
                                // (keeps small weights and their lo parts out of fp16's subnormal range)
@@ -53,6 +58,7 @@ struct Model {
   int arch = 0, n_stages = 0, n_heads = 0, n_logits = 0;
   bool exact = false;
   bool w2 = false;          // fast tiling, two weight planes (MLT_MODEL_W2)
+  bool xl = false;          // exact-lite (MLT_MODEL_XLITE): `exact` is set as well (two activation planes, the exact tiling); the 3x3 / 1x1 convs carry FP8 lo planes
   int planes[5] = {0, 0, 0, 0, 0};
   PackedConv stem;
   PackedConv stem_b;        // fast arithmetic: the composed first layer packed again for stem_block_kernel (mlt_model.cpp: pack_stem_b)
@@ -62,7 +68,7 @@ struct Model {
   int rounding = 0;         // MLT_MODEL_FAST: the rounding realisation of the 3x3 layers (build_model)
 };
 
-enum { MLT_MODEL_FAST = 0, MLT_MODEL_EXACT = 1, MLT_MODEL_W2 = 2 };  // tap-diffused single fp16 plane / (hi, lo) planes on the exact tiling / (hi, lo) planes on the fast tiling
+enum { MLT_MODEL_FAST = 0, MLT_MODEL_EXACT = 1, MLT_MODEL_W2 = 2, MLT_MODEL_XLITE = 3 };  // tap-diffused single fp16 plane / (hi, lo) planes on the exact tiling / (hi, lo) planes on the fast tiling
 // rounding (MLT_MODEL_FAST only, round 4): which realisation of the tap-diffused rounding the 3x3 layers get -- 0: raster tap order, error
 // reset per (cout, cin) pair (rounds 1-3); 1: raster, error carried across cin; 2: reversed taps; 3: column-major taps; 4: spiral from the
 // centre; 5: serpentine, carried across cin.  Every one keeps each weight within one ulp and cancels the rounding error along spatially

@@ -25,6 +25,9 @@ struct TierPricer {
   virtual ~TierPricer() {}
   // rounding: which realisation of the single-pass weights' tap-diffused rounding (0 = the default)
   virtual int price(unsigned w2_units, unsigned x_units, int rounding, TierPrice &out) = 0;
+  // the whole model in the exact-lite arithmetic (round 5: Wh*Xh in fp16, both cross terms in one scaled FP8 MFMA; |dlogit| ~ 1/20 of the single
+  // pass's, 1.15 x the exact arithmetic's rate).  > 0: an error code; < 0: this pricer has no such tier (the search skips it)
+  virtual int price_lite(TierPrice &out) { (void)out; return -1; }
 };
 
 struct TierRules {
@@ -46,11 +49,12 @@ struct TierForce {
   int x_mask = -1;         // MLT_X_MASK: exactly this stage mask exact, the others hi+lo weights
   int w2_units = -1;       // MLT_W2_UNITS: exactly this unit mask in hi+lo weights
   int small_prefix = -1;   // MLT_SMALL_PREFIX: small models, exactly the prefix of k single-pass stages
-  bool no_roundings = false, no_w2 = false, no_xmix = false, no_w2_units = false, no_x_units = false;
+  bool no_roundings = false, no_w2 = false, no_xmix = false, no_w2_units = false, no_x_units = false, no_lite = false;
 };
 
 struct TierChoice {
   bool exact = false;      // no candidate meets the contract: the whole model in the exact arithmetic
+  bool lite = false;       // no fp16 tier meets the contract, the exact-lite arithmetic does: the whole model runs it (tried last: the mixed tiers are faster)
   bool w2 = false;         // a middle tier was admitted (w2_units / x_units say where)
   unsigned w2_units = 0, x_units = 0;
   int rounding = 0;        // realisation of the single-pass weights the search ended on
@@ -183,8 +187,17 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
     P = kept;
   }
   (void)x_mask;
-  if (ok) { out.w2 = true; out.w2_units = w2u; out.x_units = xu; out.price = P; }
-  else { out.exact = true; out.price = P1; }
+  if (ok) { out.w2 = true; out.w2_units = w2u; out.x_units = xu; out.price = P; return 0; }
+  // 6. (round 5) the exact-lite arithmetic everywhere, before the exact one
+  if (!F.no_lite && !force_mask && !force_x) {
+    TierPrice PL;
+    ++out.priced;
+    rc = pr.price_lite(PL);
+    if (rc > 0) return rc;
+    if (rc == 0 && R.within(PL)) { out.lite = true; out.price = PL; return 0; }
+    if (rc < 0) --out.priced;
+  }
+  out.exact = true; out.price = P1;
   return 0;
 }
 
@@ -219,7 +232,18 @@ inline int search_tier_small(TierPricer &pr, const TierRules &R, const TierForce
     }
   }
   out.price = P;
-  if (!ok) { out.exact = true; out.w2 = false; out.w2_units = out.x_units = 0; }
+  if (!ok) {
+    out.w2 = false; out.w2_units = out.x_units = 0;
+    if (!F.no_lite && !force_k) {  // (round 5) the exact-lite arithmetic before the exact one
+      TierPrice PL;
+      ++out.priced;
+      rc = pr.price_lite(PL);
+      if (rc > 0) return rc;
+      if (rc == 0 && R.within(PL)) { out.lite = true; out.price = PL; return 0; }
+      if (rc < 0) --out.priced;
+    }
+    out.exact = true;
+  }
   return 0;
 }
 
@@ -227,9 +251,10 @@ inline int search_tier_small(TierPricer &pr, const TierRules &R, const TierForce
 
 // CPU test hook (exported from libmltcnn_hip.so, NOT part of include/mltcnn.h): the search over a caller-supplied pricer.
 //   kind 0: search_tier_128 (n = realisations of the rounding), kind 1: search_tier_small (n = stages)
-//   price_cb(user, w2_units, x_units, rounding, out[3] = {rms, max, tail}) -> 0 or an error code (returned unchanged)
-//   force[11] = {rounding, w2_mask, x_mask, w2_units, small_prefix, no_roundings, no_w2, no_xmix, no_w2_units, no_x_units, reserved}; NULL = nothing forced
-//   result[8] <- {exact, w2, w2_units, x_units, rounding, priced, 0, 0}; figures[3] <- {rms, max, tail} of the choice
+//   price_cb(user, w2_units, x_units, rounding, out[3] = {rms, max, tail}) -> 0 or an error code (returned unchanged); the exact-lite tier is
+//   priced as price_cb(user, ~0u, ~0u, 0, out), where a NEGATIVE return means "no such tier"
+//   force[11] = {rounding, w2_mask, x_mask, w2_units, small_prefix, no_roundings, no_w2, no_xmix, no_w2_units, no_x_units, no_lite}; NULL = nothing forced
+//   result[8] <- {exact, w2, w2_units, x_units, rounding, priced, lite, 0}; figures[3] <- {rms, max, tail} of the choice
 extern "C" int mlt_tier_search_run(int kind, int n, float tolerance, float max_frac, const int *force,
                                    int (*price_cb)(void *user, unsigned w2_units, unsigned x_units, int rounding, float *out3), void *user,
                                    int *result, float *figures);

@@ -67,6 +67,9 @@ enum {
 #define MLT_FLAG_DECISION_GUARD 0x4u    /* ABI <= 3: opt-in to the decision guard.  Since ABI 4 the guard is the default: accepted, no effect */
 #define MLT_FLAG_NO_FLAT_GUARD 0x8u    /* fast arithmetic without the flat-content guard (measurement only) */
 #define MLT_FLAG_NO_CALIBRATION 0x10u  /* keep the fast arithmetic whatever the weight set (measurement only) */
+#define MLT_FLAG_EXACT_LITE 0x40u      /* ABI 4 (round 5, measurement): sizes configured exact (MLT_FLAG_EXACT_128; 64/32/16 with MLT_FLAG_NO_CALIBRATION) run the
+                                          "exact-lite" arithmetic: Wh*Xh in fp16, the two cross terms Wl*Xh + Wh*Xl as ONE scaled FP8 MFMA per tap and 32 channels
+                                          (2 fp16-equivalent MFMAs per product instead of 3; |dlogit| ~ 1/20 of the single pass's) */
 #define MLT_FLAG_NO_DECISION_GUARD 0x20u /* ABI 4: fast arithmetic without the decision guard (measurement only: a split whose reference margin is
                                           below ~2 x tolerance may then differ from the reference's) */
 
@@ -129,7 +132,8 @@ mlt_ctx *mlt_device_ctx(mlt_ctx *ctx, int index);
  * of the fused kernels, in a SUBSET of the four stages: the 15 subsets are priced in the order of
  * their measured cost and the cheapest one that meets the contract is kept (mlt_arith_info.w2_stages); failing those, the tiers that
  * put one to three stages into the exact arithmetic and the others into (hi, lo) weights (.x_stages), cheapest first -- and a size that
- * meets the contract with none of them runs exact (mlt_arithmetic reports the outcome).  The
+ * meets the contract with none of them is priced in the exact-lite arithmetic (mlt_arith_info.exact == 5; what a TRAINED-like weight set lands
+ * on: profiles/r05d_trained_family.txt) and runs exact only if that fails too (mlt_arithmetic reports the outcome).  The
  * admission is STATISTICAL (synthetic content, Gaussian-tail factor), not a bound: "within 1e-3" is calibrated, not proven. */
 int mlt_load_weights(mlt_ctx *ctx, int size, const void *blob, size_t bytes);
 
@@ -140,7 +144,9 @@ typedef struct mlt_arith_info {
   uint32_t struct_size;   /* in: sizeof(mlt_arith_info) of the caller */
   int32_t exact;          /* 0: fast; 1: exact ((hi, lo) pairs for weights and activations); 2: (hi, lo) weights on fp16 activations in
                              every stage; 3: (hi, lo) weights in SOME stages (w2_stages), single pass in the others; 4: the exact arithmetic in the
-                             stages of x_stages, (hi, lo) weights in the others (w2_stages) */
+                             stages of x_stages, (hi, lo) weights in the others (w2_stages); 5 (round 5): exact-lite in every stage -- (hi, lo) pairs
+                             with Wh*Xh in fp16 and both cross terms Wl*Xh + Wh*Xl in ONE scaled FP8 MFMA per tap and 32 channels: 2 fp16-equivalent
+                             MFMAs per product instead of 3, |dlogit| ~ 1/20 of the single pass's (1e-5 rms); tried after every fp16 tier, before exact */
   int32_t calibrated;     /* 1: the calibration ran for this size */
   float calib_rms, calib_max; /* |dlogit| of the chosen non-exact tier (or of the fast one if exact was chosen) vs exact over the calibration CUs:
                                  worst rms pooled per content class / per head, and the overall maximum */

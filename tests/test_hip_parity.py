@@ -361,9 +361,21 @@ def test_load_time_calibration_picks_the_arithmetic(gpu):
     for i in range(4):
         s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
         assert s1 == s10[i][0] and np.array_equal(l1, s10[i][1])
+    # a tolerance no fp16 tier meets: the exact-lite arithmetic (round 5; |dlogit| ~ 1e-5 rms) is tried before the exact one ...
     tight = _ctx(pkg, size, b10, tolerance=2e-4)
-    assert tight.arithmetic(size)["exact"] == 1
-    for c in (m, fresh, tight):
+    a = tight.arithmetic(size)
+    print("tolerance 2e-4:", a)
+    assert a["exact"] == 5 and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 2e-4 and a["calib_max"] <= 0.65 * 2e-4 and a["flat_guard"] == 0 and a["decision_guard"] == 1
+    sl3, ll3 = tight.predict_batch(org, pred, poc, qp)
+    r10, r10s = oracle.Oracle(b10).forward(org, pred, poc, qp)
+    assert np.abs(ll3 - r10).max() <= 2e-4 and np.array_equal(sl3, r10s)
+    for i in range(4):
+        s1, l1 = tight.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        assert s1 == sl3[i] and np.array_equal(l1, ll3[i]), "exact-lite: single-CU path differs from the batch path"
+    # ... and one that it does not meet either runs exact
+    tighter = _ctx(pkg, size, b10, tolerance=2e-5)
+    assert tighter.arithmetic(size)["exact"] == 1
+    for c in (m, fresh, tight, tighter):
         c.close()
 
 
@@ -432,7 +444,7 @@ def test_small_models_calibrated_prefix(gpu):
             m = _ctx(pkg, size, blob)
             a = m.arithmetic(size)
             print(f"size {size} seed {seed}:", a)
-            assert a["exact"] in (1, 4)
+            assert a["exact"] in (1, 4, 5)   # (5, round 5: no prefix passes but the exact-lite arithmetic does -- 64 x 64 with seed 13)
             seen.add(a["exact"])
             if a["exact"] == 4:
                 # (every stage behind layer0 exact; of layer0 at most one launch unit -- the 64 x 64 model keeps layer0.1 exact)
@@ -442,9 +454,11 @@ def test_small_models_calibrated_prefix(gpu):
             ref, ref_split = oracle.Oracle(blob).forward(org, pred, poc, qp, threads=8)
             s, l = m.predict_batch(org, pred, poc, qp)
             assert np.abs(l - ref).max() <= LOGIT_TOL
-            assert np.abs(l[5] - ref[5]).max() <= 2e-5
+            # (the exact-lite tier has no flat-content failure mode -- its weights keep their lo parts -- and therefore no flat guard: the constant CU
+            # carries the tier's own error, a fifth of the contract at most)
+            assert np.abs(l[5] - ref[5]).max() <= (2e-4 if a["exact"] == 5 else 2e-5)
             sl = head_slices(oracle.Oracle(blob).head_classes)[0]
-            check_splits(s, ref, ref_split, sl, a["exact"] == 1, LOGIT_TOL, f"{size}/{seed}")
+            check_splits(s, ref, ref_split, sl, a["exact"] == 1 or a["decision_guard"] == 1, LOGIT_TOL, f"{size}/{seed}")
             for i in (0, 5, 11):
                 s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
                 assert s1 == s[i] and np.array_equal(l1, l[i]), "single-CU path differs from the batch path"
@@ -995,8 +1009,8 @@ def test_calibrate_on_caller_content(gpu):
     m.calibrate(size, org[:8], pred[:8], poc[:8], qp[:8], replace=True)
     a3 = m.arithmetic(size)
     assert a3["calib_cus"] == 0 and a3["exact"] == 0 and a3["calib_max"] == 0.0
-    # a tolerance no fp16 tier meets: the caller's CUs take the size to the exact arithmetic like the synthetic ones do
-    t = _ctx(pkg, size, blob, tolerance=2e-4)
+    # a tolerance no tier below it meets: the caller's CUs take the size to the exact arithmetic like the synthetic ones do
+    t = _ctx(pkg, size, blob, tolerance=2e-5)
     t.calibrate(size, org, pred, poc, qp, replace=True)
     assert t.arithmetic(size)["exact"] == 1
     with pytest.raises(pkg.MltError) as ei:
@@ -1015,4 +1029,47 @@ def test_calibrate_on_caller_content(gpu):
     r64, _ = Oracle(b64).forward(o64[:16], p64[:16], poc[:16], qp[:16], threads=8)
     assert np.abs(c64.predict_batch(o64[:16], p64[:16], poc[:16], qp[:16])[1] - r64).max() <= LOGIT_TOL
     for c in (m, t, e, c64):
+        c.close()
+
+
+def test_exact_lite_arithmetic_against_the_oracle(gpu):
+    """Round 5: the exact-lite arithmetic forced for every conv (MLT_FLAG_EXACT_128 | MLT_FLAG_EXACT_LITE: conv_mfma_kernel
+    NSPLIT = 6 -- Wh*Xh in fp16, Wl*Xh + Wh*Xl as one v_mfma_scale_f32_32x32x64_f8f6f4 per tap and 32 channels with per-K-block E8M0 scales)
+    on the golden fixtures' weight sets: |dlogit| <= 2e-4 on every fixture (measured <= 1.3e-4, rms ~1e-5: 1/20 of the single pass), the
+    same bits through the large tiles and the small-launch variants, and strictly between the exact and the single-pass arithmetic in error."""
+    from oracle import Oracle
+    pkg = gpu
+    size = 128
+    golden = load_golden(size)
+    worst = 0.0
+    for case in golden["cases"]:
+        blob, org, pred, poc, qp, exp, exp_arg = materialise(pkg, golden, case)
+        m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128 | pkg.capi.FLAG_EXACT_LITE)
+        s, l = m.predict_batch(org, pred, poc, qp)
+        err = float(np.abs(l - exp).max())
+        worst = max(worst, err)
+        assert err <= 2e-4, (case["name"], err)
+        s1, l1 = m.predict(org[0], pred[0], int(poc[0]), int(qp[0]))
+        assert s1 == s[0] and np.array_equal(l1, l[0]), case["name"]
+        m.close()
+    print(f"exact-lite on {len(golden['cases'])} fixtures: worst |dlogit| {worst:.2e}")
+    # bit-identity across launch sizes (latency variants <= 16 k output pixels vs the large tiles) and against the oracle on a larger batch
+    blob = pkg.weights.synthetic_blob(0, 22)
+    n = 300
+    org, pred = pkg.synth.make_patches_bulk(size, n, 515)
+    poc, qp = pkg.synth.make_scalars(n, 515)
+    m = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128 | pkg.capi.FLAG_EXACT_LITE)
+    s, l = m.predict_batch(org, pred, poc, qp)
+    for k in (1, 17, 65, 257):
+        sk, lk = m.predict_batch(org[:k], pred[:k], poc[:k], qp[:k])
+        assert np.array_equal(lk, l[:k]) and np.array_equal(sk, s[:k]), k
+    ref, _ = Oracle(blob).forward(org[:64], pred[:64], poc[:64], qp[:64], threads=8)
+    e_lite = float(np.abs(l[:64] - ref).max())
+    ex = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
+    e_exact = float(np.abs(ex.predict_batch(org[:64], pred[:64], poc[:64], qp[:64])[1] - ref).max())
+    fa = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_CALIBRATION | pkg.capi.FLAG_NO_FLAT_GUARD | pkg.capi.FLAG_NO_DECISION_GUARD)
+    e_fast = float(np.abs(fa.predict_batch(org[:64], pred[:64], poc[:64], qp[:64])[1] - ref).max())
+    print(f"seed 22, 64 CUs vs the oracle: exact {e_exact:.2e}  exact-lite {e_lite:.2e}  single pass {e_fast:.2e}")
+    assert e_exact <= 2e-5 and e_lite <= 2e-4 and e_lite < 0.25 * e_fast
+    for c in (m, ex, fa):
         c.close()

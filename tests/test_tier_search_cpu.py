@@ -25,11 +25,18 @@ def run(pkg):
     lib = pkg.capi.load_library()
     lib.mlt_tier_search_run.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), CB, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
 
-    def go(kind, n, table, default=BAD, force=None, max_frac=0.0, fail_at=None):
-        """table: {(w2_units, x_units, rounding): (rms, max, tail)} or a callable; -> (result dict, list of priced configurations)"""
+    def go(kind, n, table, default=BAD, force=None, max_frac=0.0, fail_at=None, lite=BAD):
+        """table: {(w2_units, x_units, rounding): (rms, max, tail)} or a callable; lite: the figures of the exact-lite tier (priced as w2 = x = ~0, recorded as
+        the string "lite"; None: the pricer has no such tier) -> (result dict, list of priced configurations)"""
         calls = []
 
         def cb(_, w2u, xu, r, out):
+            if w2u == 0xFFFFFFFF and xu == 0xFFFFFFFF:
+                if lite is None:
+                    return -1
+                calls.append("lite")
+                out[0], out[1], out[2] = lite
+                return 5 if (fail_at is not None and len(calls) == fail_at) else 0
             calls.append((w2u, xu, r))
             if fail_at is not None and len(calls) == fail_at:
                 return 5
@@ -40,9 +47,9 @@ def run(pkg):
         f = None
         if force:
             f = (C.c_int * 11)(*[force.get(k, d) for k, d in (("rounding", -1), ("w2_mask", -1), ("x_mask", -1), ("w2_units", -1), ("small_prefix", -1),
-                                                            ("no_roundings", 0), ("no_w2", 0), ("no_xmix", 0), ("no_w2_units", 0), ("no_x_units", 0), ("_", 0))])
+                                                            ("no_roundings", 0), ("no_w2", 0), ("no_xmix", 0), ("no_w2_units", 0), ("no_x_units", 0), ("no_lite", 0))])
         rc = lib.mlt_tier_search_run(kind, n, TOL, max_frac, f, CB(cb), None, res, fig)
-        return dict(rc=rc, exact=res[0], w2=res[1], w2_units=res[2], x_units=res[3], rounding=res[4], priced=res[5], rms=fig[0], max=fig[1], tail=fig[2]), calls
+        return dict(rc=rc, exact=res[0], w2=res[1], w2_units=res[2], x_units=res[3], rounding=res[4], priced=res[5], lite=res[6], rms=fig[0], max=fig[1], tail=fig[2]), calls
     return go
 
 
@@ -144,11 +151,27 @@ def test_tier_below_exact_and_its_three_refinements(run):
 def test_nothing_meets_the_contract_runs_exact_with_the_single_pass_figures(run):
     r, calls = run(0, 2, lambda w, x, rr: (2.5e-4, 8e-4, 4.0) if (w, x, rr) == (0, 0, 1) else BAD)
     assert r["exact"] == 1 and r["w2"] == 0 and r["w2_units"] == 0 and r["x_units"] == 0 and r["rounding"] == 1
-    assert abs(r["rms"] - 2.5e-4) < 1e-9 and len(calls) == 3 + 15 + 11
+    assert abs(r["rms"] - 2.5e-4) < 1e-9 and len(calls) == 3 + 15 + 11 + 1 and calls[-1] == "lite" and r["lite"] == 0
     r, calls = run(0, 1, {}, force={"no_w2": 1, "no_roundings": 1})
-    assert r["exact"] == 1 and calls == [(0, 0, 0)]
-    r, calls = run(0, 1, {}, force={"no_xmix": 1, "no_roundings": 1})
+    assert r["exact"] == 1 and calls == [(0, 0, 0), "lite"]
+    r, calls = run(0, 1, {}, force={"no_xmix": 1, "no_roundings": 1, "no_lite": 1})
     assert r["exact"] == 1 and len(calls) == 1 + 15
+
+
+def test_exact_lite_is_the_last_tier_before_exact(run):
+    """Round 5: the exact-lite arithmetic (fp16 hi x hi + both cross terms in one scaled FP8 MFMA) is priced after every fp16 tier has failed -- the
+    mixed tiers are faster -- and before the exact arithmetic; a pricer without such a tier (negative return) is simply skipped."""
+    r, calls = run(0, 1, {}, force={"no_roundings": 1}, lite=GOOD)
+    assert (r["exact"], r["lite"], r["w2"], r["w2_units"], r["x_units"]) == (0, 1, 0, 0, 0) and calls[-1] == "lite" and len(calls) == 1 + 15 + 11 + 1
+    assert abs(r["rms"] - GOOD[0]) < 1e-9 and r["priced"] == len(calls)
+    r, calls = run(0, 1, {(0, 0, 0): BAD, (units(0x2), 0, 0): GOOD}, force={"no_roundings": 1}, lite=GOOD)
+    assert r["lite"] == 0 and r["w2"] == 1 and "lite" not in calls                      # an fp16 tier that passes wins
+    r, calls = run(0, 1, {}, force={"no_roundings": 1}, lite=None)
+    assert r["exact"] == 1 and r["lite"] == 0 and "lite" not in calls and r["priced"] == len(calls)
+    r, calls = run(1, 5, {}, max_frac=0.5, lite=(1e-4, 4.9e-4, 4.0))
+    assert (r["exact"], r["lite"]) == (0, 1) and calls[-1] == "lite"                    # the small models: after the prefixes and layer0's variants
+    r, calls = run(1, 5, {}, max_frac=0.5, lite=(1e-4, 5.1e-4, 4.0))
+    assert (r["exact"], r["lite"]) == (1, 0)                                            # ... under THEIR rule (largest error <= 0.5 x tolerance)
 
 
 def test_forced_masks_are_kept_whatever_they_measure(run):
@@ -165,7 +188,7 @@ def test_small_models_prefixes_then_layer0_variants(run):
     rest = units(allm & ~1)
     order = [(0, units(allm & ~((1 << k) - 1))) for k in (4, 3, 2, 1)]
     r, calls = run(1, 5, {}, max_frac=0.5)
-    assert [c[:2] for c in calls] == order + [(units(1), units(0x1E)), (0, rest | 2), (0, rest | 1)] and r["exact"] == 1
+    assert [c[:2] for c in calls[:-1]] == order + [(units(1), units(0x1E)), (0, rest | 2), (0, rest | 1)] and calls[-1] == "lite" and r["exact"] == 1
     r, calls = run(1, 5, {(0, units(0x1C), 0): GOOD}, max_frac=0.5)
     assert len(calls) == 3 and (r["exact"], r["x_units"], r["w2_units"]) == (0, units(0x1C), 0)
     r, calls = run(1, 5, {(units(1), units(0x1E), 0): GOOD}, max_frac=0.5)
@@ -182,5 +205,7 @@ def test_small_models_prefixes_then_layer0_variants(run):
 def test_a_failing_pricer_stops_the_search_with_its_code(run):
     r, calls = run(0, 6, {}, fail_at=4)
     assert r["rc"] == 5 and len(calls) == 4
+    r, calls = run(0, 1, {}, force={"no_roundings": 1, "no_w2": 1}, fail_at=2)   # ... the exact-lite pricing included
+    assert r["rc"] == 5 and calls == [(0, 0, 0), "lite"]
     r, calls = run(1, 5, {}, fail_at=1)
     assert r["rc"] == 5 and len(calls) == 1
