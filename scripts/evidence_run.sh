@@ -6,7 +6,8 @@
 # 3. HBM traffic: separate --pmc FETCH_SIZE / WRITE_SIZE passes       -> fetch/, write/  (MI355X_MICROARCH.md HBM section)
 # 4. MFMA / LDS / wait counters, one --pmc pass per counter group     -> pmc/<group>/
 # 5. round 4: the other arithmetic tiers (weight seeds 11 / 13 / 23 / 24: hi+lo weights in some stages; 12 / 21 / 22: exact stages; --flags 1: exact), the encoder's
-#    configuration (decision guard), content mixes (25 % flat-guard content, natural statistics), the small CU sizes, the one-CU timeline
+#    configuration (decision guard: the default since ABI 4; --flags 0x20 = without), exact-lite (--flags 0x41), the trained-like weight family when
+#    $out/trained1.mltw exists (tools/train_synth_weights.py), content mixes (25 % flat-guard content, natural statistics), the small CU sizes, the one-CU timeline
 # Counter passes never combine --pmc with --stats / trace domains other than --kernel-trace.
 set -u
 tag=${1:-r04k}
@@ -24,10 +25,12 @@ for grp in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ
 done
 for s in 11 13 23 24 12 21 22; do python3 bench.py --no-cpu-baseline --weight-seed $s > $out/bench_seed$s.json 2>> $out/bench.err; done
 python3 bench.py --no-cpu-baseline --flags 1 --steps 20 --warmup 5 > $out/bench_exact.json 2>> $out/bench.err
-python3 bench.py --no-cpu-baseline --flags 4 > $out/bench_decision_guard.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --flags 0x41 --steps 20 --warmup 5 > $out/bench_exact_lite.json 2>> $out/bench.err   # round 5: exact-lite forced (tier 5)
+python3 bench.py --no-cpu-baseline --flags 0x20 > $out/bench_no_decision_guard.json 2>> $out/bench.err                     # ABI 4: the guard is the default; this is the round-4 headline configuration
+if [ -f $out/trained1.mltw ]; then python3 bench.py --no-cpu-baseline --weights-blob $out/trained1.mltw --steps 20 --warmup 5 > $out/bench_trained_family.json 2>> $out/bench.err; fi
 python3 bench.py --no-cpu-baseline --flat-frac 0.25 --steps 20 --warmup 5 > $out/bench_flat25.json 2>> $out/bench.err
 python3 bench.py --no-cpu-baseline --content natural > $out/bench_natural.json 2>> $out/bench.err
-python3 bench.py --no-cpu-baseline --content natural --flags 4 > $out/bench_natural_decision_guard.json 2>> $out/bench.err
+python3 bench.py --no-cpu-baseline --content natural --flags 0x20 > $out/bench_natural_no_decision_guard.json 2>> $out/bench.err
 for s in 64 32 16; do python3 bench.py --size $s > $out/bench_s$s.json 2>> $out/bench.err; done
 rocprofv3 --kernel-trace --output-format csv -d $out/lat -o out -- python3 scripts/latency_run.py 60 10 0 > $out/lat.log 2>&1
 python3 scripts/latency_run.py 80 10 4 > $out/latency_modes.txt 2>&1

@@ -123,3 +123,15 @@ def test_bench_gpus_flag_starts_its_own_ranks(monkeypatch, capsys):
     assert bench.launch_ranks(args) != 0
     monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=7, stdout='{"a": 1}\n'))
     assert bench.launch_ranks(args) == 7
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Inside a torchrun launch (WORLD_SIZE set) `--gpus N` must equal the world size: bench.py exits 2 with a message BEFORE any GPU call
+    (this container has no GPU -- reaching torch.cuda would trip the `no CPU fallback` assertion instead) and prints no JSON line."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert "--gpus 8 but WORLD_SIZE=2" in r.stderr and "{" not in r.stdout

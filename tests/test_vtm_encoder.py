@@ -251,7 +251,9 @@ def test_ra_tool_set_on_the_gpu_all_four_cu_sizes_from_the_real_call_site(pkg, t
     accepts the dump.  The full-size run (832 x 480 x 17, four QPs) is profiles/r05_ra_eval_gpu/."""
     import torch
     assert torch.cuda.is_available()
-    r, summ = _run_ra_eval(str(tmp_path), "gpu", 448, 320, 5)
+    # 432 x 304 = (3 x 128 + 48) x (2 x 128 + 48): the partial CTUs on both borders are split implicitly down to whole 32 x 32 and 16 x 16 CUs, so
+    # every CU size reaches the call site whatever the seeded weights decide for the sizes above it
+    r, summ = _run_ra_eval(str(tmp_path), "gpu", 432, 304, 5)
     print(r.stdout[-2500:])
     assert summ["ok"] and r.returncode == 0, summ["checks"]
     assert summ["checks"]["32"]["n3_batch_equals_serial"] and summ["checks"]["32"]["batch_decodes_to_recon"]
