@@ -458,6 +458,29 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
 
+// All of layer0 of 128 x 128 CUs in one launch (layer0_stream_kernel): bit-identical to run_stem_block + run_block32, b0 never reaches HBM.
+int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
+                      long pred_rs, long pred_cs, void *y, int32_t *d_flat, bool flat_is_clear) {
+  const mlt::PackedConv &c2 = m0.blocks[0][0].conv2;
+  const mlt::Block &B1 = m1.blocks[0][1];
+  Layer0Args a{};
+  a.org = d_org; a.pred = d_pred; a.org_row_stride = org_rs; a.org_cu_stride = org_cs; a.pred_row_stride = pred_rs; a.pred_cu_stride = pred_cs;
+  a.w = m0.stem_b.d_w; a.w2 = c2.d_w; a.w3 = B1.conv1.d_w; a.w4 = B1.conv2.d_w;
+  a.bias = m0.stem.d_bias; a.bias_sc = m0.stem.d_bias_sc; a.bias2 = c2.d_bias; a.bias3 = B1.conv1.d_bias; a.bias4 = B1.conv2.d_bias;
+  a.y = y; a.flat = d_flat; a.acc_scale = m0.stem.acc_scale; a.n = n;
+  if (d_flat && !flat_is_clear) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP0"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int grid_x = n > wg_cap ? wg_cap : n;
+  const double px = (double)n * 64 * 64;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_layer0_stream(a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  return debug_dump(ctx, "block_s1_32_h64(conv1+conv2)", y, (size_t)px * 32 * 2);  // (the dump carries the two-launch form's name: same tensor)
+}
+
 // Fused identity BasicBlock of the 32-channel stage (fast arithmetic, H >= 32): conv1 -> LDS -> conv2 + residual.
 int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, void *y) {
   Block32Args a{};
@@ -621,6 +644,14 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
       HIP_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
       if ((rc = L.prof_end(e1))) return rc;
+    }
+    // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups)
+    static const int l0_min = [] { const char *e = tuning_env("MLT_L0_STREAM_MIN"); return tuning_env("MLT_NO_L0_STREAM") ? 0 : e ? std::atoi(e) : 256; }();
+    if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && l0_min > 0 && n >= l0_min) {
+      if ((rc = run_layer0_stream(ctx, ms, mt, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, outs[s], d_flat, flat_is_clear))) return rc;
+      cur = outs[s];
+      h = ho;
+      continue;
     }
     if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
       hout = ho;

@@ -95,6 +95,21 @@ struct StemBlockArgs {
   float scale2;
 };
 
+// All of layer0 of 128 x 128 CUs in one launch (layer0_stream_kernel, round 5): stem_block_kernel's and block32_kernel's arithmetic, streamed row by
+// row through LDS rings by one persistent 16-wave workgroup per CU -- b0 never reaches HBM, no halo is staged or computed twice.
+#define MLT_L0_LDS_BYTES 145856  /* 3 rings x 8 map rows + zero row (66 px x 80 B), 16 + 1 raw rows (136 dwords), biases, 4 KiB of first-layer k-steps */
+struct Layer0Args {
+  const int16_t *org, *pred;   // Pel planes, 128 x 128 per CU
+  long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements (8-byte aligned quads: see stem_block_kernel)
+  const void *w;               // composed first-layer weights (StemBlockArgs.w)
+  const void *w2, *w3, *w4;    // layer0.0.conv2, layer0.1.conv1, layer0.1.conv2: packed fp16, 18 KiB each (fast plane)
+  const float *bias, *bias_sc, *bias2, *bias3, *bias4;
+  void *y;                     // layer0 output [n][64][64][32] fp16
+  int32_t *flat;               // NULL, or [n] zero-initialised (flat-content guard statistic, as StemBlockArgs.flat)
+  float acc_scale;             // composed-weight storage scale
+  int n;
+};
+
 // Fused chain of stride-1 3x3 convs on whole samples (chain_kernel): the BasicBlock tail of a stage,
 //   b0 = relu(bn2(conv2(t)) + sc) ; t1 = relu(bn1(conv1(b0))) ; out = relu(bn2(conv2(t1)) + b0)      (arch:52-57)
 // with every intermediate kept on chip (activations in LDS, b0 as the residual in registers).
@@ -198,4 +213,5 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st);  // nsplit as mlt_launch_conv
 hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st);     // w2: hi+lo weights (8 x 32 tiles)
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st);
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

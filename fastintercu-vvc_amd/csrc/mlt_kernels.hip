@@ -268,6 +268,7 @@ template <int Q> __device__ __forceinline__ half4 act_quad(const float16v &A, fl
 #include "mlt_conv_kernels.inc"   // conv_epilogue, conv_mfma_kernel, conv_ring_dma_kernel
 #include "mlt_chain_kernel.inc"   // chain_kernel (+ KARG)
 #include "mlt_front_kernels.inc"  // block32_kernel, stem5_kernel, stem_block_kernel
+#include "mlt_layer0_kernel.inc"  // layer0_stream_kernel
 #include "mlt_tail_kernels.inc"   // heads_kernel, flat_stat / guard kernels
 
 // ---------------------------------------------------------------------------------------------
@@ -776,6 +777,13 @@ hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hi
   }
   if (hipError_t e = ensure_big_lds(stem_block_kernel<false>, once[0]); e != hipSuccess) return e;
   hipLaunchKernelGGL(stem_block_kernel<false>, dim3(grid_x), dim3(128 * CFG_SB_NWS), lds, st, a);  // one workgroup per CU, two pipeline stages inside
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, int grid_x, hipStream_t st) {
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(layer0_stream_kernel, once); e != hipSuccess) return e;
+  hipLaunchKernelGGL(layer0_stream_kernel, dim3(grid_x), dim3(1024), MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot: 4 stages x 4 row units
   return hipGetLastError();
 }
 

@@ -1073,3 +1073,26 @@ def test_exact_lite_arithmetic_against_the_oracle(gpu):
     assert e_exact <= 2e-5 and e_lite <= 2e-4 and e_lite < 0.25 * e_fast
     for c in (m, ex, fa):
         c.close()
+
+
+def test_layer0_stream_is_bit_identical(gpu):
+    """Round 5: batches of >= 256 CUs of 128 x 128 run ALL of layer0 in one streaming launch (layer0_stream_kernel: four row stages handing rows to
+    each other through LDS rings, b0 never in HBM); smaller batches keep the two tiled launches (stem_block_kernel -> block32_kernel).  Same
+    arithmetic in the same order: the logits must agree bit for bit -- 301 CUs (workgroups with one CU and with two; pipeline fill and drain across
+    the CU boundary) against the same CUs in sub-batches of 100, flat CUs included (the guard statistic is gathered by the streaming kernel too)."""
+    pkg = gpu
+    n = 301
+    blob = pkg.weights.synthetic_blob(0, 10)
+    org, pred = pkg.synth.make_patches_bulk(128, n, 5150)
+    poc, qp = pkg.synth.make_scalars(n, 5150)
+    org[7] = 512; pred[7] = 512                       # constant CU (flat-content guard)
+    org[300] = 0; pred[300] = 1023                    # extreme residual in the last CU (a workgroup's only CU)
+    m = _ctx(pkg, 128, blob)
+    assert m.arithmetic(128)["exact"] == 0
+    s, l = m.predict_batch(org, pred, poc, qp)
+    for a in range(0, n, 100):
+        b = min(n, a + 100)
+        s1, l1 = m.predict_batch(org[a:b], pred[a:b], poc[a:b], qp[a:b])
+        assert np.array_equal(l1, l[a:b]) and np.array_equal(s1, s[a:b]), f"streaming layer0 differs from the tiled form in CUs {a}..{b}"
+    assert m.arithmetic(128)["guard_reruns"] >= 1
+    m.close()
