@@ -97,7 +97,7 @@ struct StemBlockArgs {
 
 // All of layer0 of 128 x 128 CUs in one launch (layer0_stream_kernel, round 5): stem_block_kernel's and block32_kernel's arithmetic, streamed row by
 // row through LDS rings by one persistent 16-wave workgroup per CU -- b0 never reaches HBM, no halo is staged or computed twice.
-#define MLT_L0_LDS_BYTES 145856  /* 3 rings x 8 map rows + zero row (66 px x 80 B), 16 + 1 raw rows (136 dwords), biases, 4 KiB of first-layer k-steps */
+#define MLT_L0_LDS_BYTES 145872  /* 3 rings x 8 map rows + zero row (66 px x 80 B), 16 + 1 raw rows (136 dwords), biases, 4 KiB of first-layer k-steps, 2 counters */
 struct Layer0Args {
   const int16_t *org, *pred;   // Pel planes, 128 x 128 per CU
   long org_row_stride, org_cu_stride, pred_row_stride, pred_cu_stride;  // in elements (8-byte aligned quads: see stem_block_kernel)

@@ -55,6 +55,15 @@ extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read(unsig
   }
   return 0;
 }
+__device__ unsigned long long g_phase_l0[4][8];      // layer0_stream_kernel: stage x {top, reads + MFMA, epilogue, step end}
+extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read_l0(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_l0), sizeof(g_phase_l0)) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long z[4][8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_l0), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
 extern "C" __attribute__((visibility("default"))) int mlt_debug_phase_read_chain(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_chain), sizeof(g_phase_chain)) != hipSuccess) return 1;
   if (reset) {

@@ -9,7 +9,8 @@ import mltcnn_pkg  # noqa: E402
 
 pkg = mltcnn_pkg.load()
 out = os.path.join(os.path.dirname(pkg.build.__file__), "_variants", "lib_phase.so")
-pkg.build.build_lib(force=True, defines=["MLT_PHASE_TIMING=1"], out=out)
+if not os.path.exists(out) or os.environ.get("MLT_PHASE_REBUILD"):
+    pkg.build.build_lib(force=True, defines=["MLT_PHASE_TIMING=1"], out=out)
 os.environ["MLT_TUNING"] = "1"
 os.environ["MLT_LIB_PATH"] = out
 import torch  # noqa: E402
@@ -57,3 +58,14 @@ for cid, nm in enumerate(["64-channel chain (default) or chain 128@16 (MLT_NO_CH
     print(f"chain_kernel {nm}: total {tot / 1e6:.1f} Mcycles (wave 0 of every workgroup, the last launch loop)")
     for k, v in zip(cnames, row):
         print(f"   {k:70s} {100.0 * v / tot:5.1f} %   {v / 1e6:9.2f} Mcyc")
+
+lbuf = (C.c_ulonglong * 32)()
+if hasattr(lib, "mlt_debug_phase_read_l0") and lib.mlt_debug_phase_read_l0(lbuf, 0) == 0:
+    lnames = ["top of the step (S1: raw commit + issue; S2: shortcut)", "fragment reads + MFMA issue", "epilogue (bias, activation, stores issued)", "step end: prefetch, wait for the stores, barrier"]
+    for st in range(4):
+        row = [lbuf[st * 8 + i] for i in range(4)]
+        tot = sum(row)
+        if tot:
+            print(f"layer0_stream_kernel stage S{st + 1} (unit 0 of every workgroup, the last launch): total {tot / 1e6:.1f} Mcycles")
+            for nm, v in zip(lnames, row):
+                print(f"   {nm:64s} {100.0 * v / tot:5.1f} %   {v / 1e6:9.2f} Mcyc")

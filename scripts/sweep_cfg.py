@@ -16,8 +16,12 @@ VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); ru
     # patch items per lane prefetched in registers, exact arithmetic (phase stamps: the synchronous tail of the commit is 36 - 45 % of the 32-channel launches)
     # (une_5 / une_5_all / une_6: profiles/r04m_sweep_exact_prefetch.txt -- CFG_UNE_32 = 5 became the default)
     # 32 -> 32 per-conv kernels on 256-pixel tiles (4 waves): the exact form then fits two workgroups per CU (78 KiB of LDS each instead of 122)
-    "x32_wp4": ["CFG_32_WP=4"],
-    "x32_wp4_une3": ["CFG_32_WP=4", "CFG_UNE_32=3"],
+    # (x32_wp4 / x32_wp4_une3 of round 4: CFG_32_WP=4 [, CFG_UNE_32=3])
+    # round 5: layer0_stream_kernel -- SIMD mapping, fragment depth, packed epilogues, knock-outs (1 no fragment reads, 2 no MFMAs, 4 no epilogues, 8 no barrier)
+    # (first form, profiles/r05o_l0_sweep1.txt: map1 0.929, pd6 0.864, pkepi 0.847, no fragment reads 0.876, no MFMAs 0.632, no epilogues 0.639, no barrier 0.859 against 0.870)
+    # (profiles/r05o_l0_sweep2.txt: wave priorities by stage 0.910 / 0.908 / 0.887, no cross-barrier prefetch 0.879 against 0.894 -- all noise)
+    # (a second accumulator for the odd items, to see whether the dependent MFMA chain limits a wave, spilled 24 VGPRs at 128; scripts/probes/mfma_chain_probe.hip
+    #  answers the question in isolation: it does not -- one wave with one chain already runs the pipe at the register-only rate)
 }
 # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
 #   "s2_wp8": ["CFG_3264_WP=8"], "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"]

@@ -86,3 +86,18 @@ def test_hi_lo_weights_front_kernels_do_not_spill(stats, kernel):
     block-invariant LDS reads out of the block loop (72 VGPRs) and spills (180 B of scratch in the first build)."""
     st = _find(stats, kernel)
     assert st["scratch"] == 0, f"{kernel}: {st['scratch']} scratch ops"
+
+
+def test_layer0_stream_kernel_keeps_its_raw_prefetch_counted_and_its_step_loops_free_of_scratch(stats):
+    """layer0_stream_kernel (round 5): 16 waves at 128 VGPRs -- the handful of spilled dwords are stage set-up values, written and read outside
+    the step loops (an A fragment reloaded from scratch per row was the first asm-pipelined build's mistake); S1's raw rows are issued RD / 2 .. RD
+    steps before they are converted, so the compiler's waits inside its step group are COUNTED (vmcnt(4..12)) apart from the one at the group's
+    end where the rows change registers -- a vmcnt(0) per step there made every step wait for an HBM round trip."""
+    st = _find(stats, "layer0_stream_kernel")
+    assert st["scratch"] <= 4, f"{st['scratch']} scratch ops"
+    assert st["glds"] == 0
+    inner = [w for w in st["waits"] if w[1] >= 1]
+    drains = [w for w in inner if "vmcnt(0)" in w[2]]
+    counted = [w for w in inner if re.search(r"vmcnt\((\d+)\)", w[2]) and int(re.search(r"vmcnt\((\d+)\)", w[2]).group(1)) >= 4]
+    assert len(drains) <= 2, f"compiler drains inside loops: {drains}"          # the LDS-clearing loop's neighbourhood at the top + the end of S1's step group
+    assert len(counted) >= 6, f"S1's raw-row waits are no longer counted: {inner}"
