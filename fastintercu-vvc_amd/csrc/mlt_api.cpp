@@ -459,8 +459,9 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
 }
 
 // All of layer0 of 128 x 128 CUs in one launch (layer0_stream_kernel): bit-identical to run_stem_block + run_block32, b0 never reaches HBM.
+// c5 != nullptr: layer1.0.conv1 + shortcut ride along as a fifth stage (layer0_stream_kernel<true>): y is not written, t -> y_t (NHWC), sc -> y_sc (chunk-major)
 int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
-                      long pred_rs, long pred_cs, void *y, int32_t *d_flat, bool flat_is_clear) {
+                      long pred_rs, long pred_cs, void *y, int32_t *d_flat, bool flat_is_clear, const mlt::PackedConv *c5 = nullptr, void *y_t = nullptr, void *y_sc = nullptr) {
   const mlt::PackedConv &c2 = m0.blocks[0][0].conv2;
   const mlt::Block &B1 = m1.blocks[0][1];
   Layer0Args a{};
@@ -468,16 +469,23 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
   a.w = m0.stem_b.d_w; a.w2 = c2.d_w; a.w3 = B1.conv1.d_w; a.w4 = B1.conv2.d_w;
   a.bias = m0.stem.d_bias; a.bias_sc = m0.stem.d_bias_sc; a.bias2 = c2.d_bias; a.bias3 = B1.conv1.d_bias; a.bias4 = B1.conv2.d_bias;
   a.y = y; a.flat = d_flat; a.acc_scale = m0.stem.acc_scale; a.n = n;
+  if (c5) { a.w5 = c5->d_w; a.bias5 = c5->d_bias; a.bias5_sc = c5->d_bias_sc; a.scale5 = c5->acc_scale; a.y_t = y_t; a.y_sc = y_sc; }
   if (d_flat && !flat_is_clear) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP0"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   const int grid_x = n > wg_cap ? wg_cap : n;
   const double px = (double)n * 64 * 64;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
+  int rc = c5 ? L.prof_begin("layer0_stream_h64(stem+layer0+layer1.0.conv1+sc)", 2.0 * px * 32 * (50 + 18 + 3 * 288) + 2.0 * (px / 4) * 64 * (288 + 32),
+                             (double)n * 128 * 128 * 4 + (px / 4) * 64 * 2 * 2, e0, e1)
+              : L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_layer0_stream(a, grid_x, ctx->stream));
+  HIP_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
+  if (c5) {
+    if ((rc = debug_dump(ctx, "conv3x3_s2_32to64_h32+sc", y_t, (size_t)(px / 4) * 64 * 2))) return rc;
+    return debug_dump(ctx, "conv3x3_s2_32to64_h32+sc_sc", y_sc, (size_t)(px / 4) * 64 * 2);
+  }
   return debug_dump(ctx, "block_s1_32_h64(conv1+conv2)", y, (size_t)px * 32 * 2);  // (the dump carries the two-launch form's name: same tensor)
 }
 
@@ -611,6 +619,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     return wants_chain(s, h_in) && !no_chain_s2 && !model_of(s, 0).w2 && !model_of(s, 1).w2 && model_of(s, 0).blocks[s][0].conv1_s2c.d_w != nullptr;
   };
   bool cur_c16 = false;  // layout of `cur`
+  bool l0_did_s2 = false;  // the layer0 streaming launch carried layer1.0.conv1 + shortcut
   for (int s = 0; s < m.n_stages; ++s) {
     int hout = h, h2;
     const bool last = s == m.n_stages - 1;
@@ -648,7 +657,15 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups)
     static const int l0_min = [] { const char *e = tuning_env("MLT_L0_STREAM_MIN"); return tuning_env("MLT_NO_L0_STREAM") ? 0 : e ? std::atoi(e) : 256; }();
     if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && l0_min > 0 && n >= l0_min) {
-      if ((rc = run_layer0_stream(ctx, ms, mt, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, outs[s], d_flat, flat_is_clear))) return rc;
+      // ... and with it the stride-2 conv + shortcut that open layer1, when the 64-channel chain follows (it wants sc chunk-major) and layer1's first
+      // unit runs the single pass too: layer0's output then never reaches HBM
+      static const bool no_f5 = tuning_env("MLT_NO_L0_S5") != nullptr;
+      const mlt::Model &m10 = model_of(1, 0);
+      const mlt::PackedConv &c5 = m10.blocks[1][0].conv1;
+      l0_did_s2 = !no_f5 && m.n_stages > 1 && !m10.exact && !m10.w2 && wants_chain(1, 64) && !wants_s2(1, 64) && m.planes[1] == 64 && !no_c16 &&
+                  c5.has_sc && c5.taps == 9 && c5.kc == 32 && c5.ct == 64 && c5.cin == 32 && c5.cout == 64 && c5.stride == 2;
+      if ((rc = run_layer0_stream(ctx, ms, mt, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, outs[s], d_flat, flat_is_clear,
+                                  l0_did_s2 ? &c5 : nullptr, pool[0], pool[1]))) return rc;
       cur = outs[s];
       h = ho;
       continue;
@@ -663,7 +680,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
         hout = ho;
         if ((rc = run_stem5(ctx, ms.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
       } else if (chain_s2) hout = ho;
-      else {
+      else if (s == 1 && l0_did_s2) {  // layer0_stream_kernel<true> wrote t (pool[0]) and sc (pool[1], chunk-major) already
+        hout = ho;
+        io.ysc_c16 = true;
+      } else {
         // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
         // (t -- the chain's input, fetched by LDS-DMA -- stays NHWC: chunk-major, the stride-2 kernel's stores gained what the chain's
         // DMA lost, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)

@@ -97,6 +97,7 @@ struct StemBlockArgs {
 
 // All of layer0 of 128 x 128 CUs in one launch (layer0_stream_kernel, round 5): stem_block_kernel's and block32_kernel's arithmetic, streamed row by
 // row through LDS rings by one persistent 16-wave workgroup per CU -- b0 never reaches HBM, no halo is staged or computed twice.
+#define MLT_L0F_LDS_BYTES 161040 /* ... with the stride-2 conv of layer1 as a fifth stage: rings of 6 / 8 / 6 / 6 rows, 64 + 64 more biases */
 #define MLT_L0_LDS_BYTES 145872  /* 3 rings x 8 map rows + zero row (66 px x 80 B), 16 + 1 raw rows (136 dwords), biases, 4 KiB of first-layer k-steps, 2 counters */
 struct Layer0Args {
   const int16_t *org, *pred;   // Pel planes, 128 x 128 per CU
@@ -108,6 +109,11 @@ struct Layer0Args {
   int32_t *flat;               // NULL, or [n] zero-initialised (flat-content guard statistic, as StemBlockArgs.flat)
   float acc_scale;             // composed-weight storage scale
   int n;
+  // fifth stage (layer0_stream_kernel<true>): layer1.0.conv1 + shortcut, packed as for conv_mfma_kernel<32, 64, 2, ...> (ct 64, kc 32, 10 taps)
+  const void *w5;
+  const float *bias5, *bias5_sc;
+  void *y_t, *y_sc;            // t [n][32][32][64] fp16 NHWC; sc chunk-major [n][4][1024][16] (ConvArgs.ysc_c16: what the 64-channel chain reads)
+  float scale5;
 };
 
 // Fused chain of stride-1 3x3 convs on whole samples (chain_kernel): the BasicBlock tail of a stage,
@@ -213,5 +219,5 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st);  // nsplit as mlt_launch_conv
 hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st);     // w2: hi+lo weights (8 x 32 tiles)
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st);
-hipError_t mlt_launch_layer0_stream(const Layer0Args &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -789,10 +789,15 @@ hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hi
   return hipGetLastError();
 }
 
-hipError_t mlt_launch_layer0_stream(const Layer0Args &a, int grid_x, hipStream_t st) {
-  static DeviceOnce once;
-  if (hipError_t e = ensure_big_lds(layer0_stream_kernel, once); e != hipSuccess) return e;
-  hipLaunchKernelGGL(layer0_stream_kernel, dim3(grid_x), dim3(1024), MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot: 4 stages x 4 row units
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x, hipStream_t st) {
+  static DeviceOnce once[2];
+  if (fuse5) {  // + layer1's stride-2 conv and shortcut as a fifth stage
+    if (hipError_t e = ensure_big_lds(layer0_stream_kernel<true>, once[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(layer0_stream_kernel<true>, dim3(grid_x), dim3(1024), MLT_L0F_LDS_BYTES, st, a);
+    return hipGetLastError();
+  }
+  if (hipError_t e = ensure_big_lds(layer0_stream_kernel<false>, once[0]); e != hipSuccess) return e;
+  hipLaunchKernelGGL(layer0_stream_kernel<false>, dim3(grid_x), dim3(1024), MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot: 4 stages x 4 row units
   return hipGetLastError();
 }
 

@@ -88,13 +88,14 @@ def test_hi_lo_weights_front_kernels_do_not_spill(stats, kernel):
     assert st["scratch"] == 0, f"{kernel}: {st['scratch']} scratch ops"
 
 
-def test_layer0_stream_kernel_keeps_its_raw_prefetch_counted_and_its_step_loops_free_of_scratch(stats):
+@pytest.mark.parametrize("form", ["true", "false"])   # with / without layer1's stride-2 conv as a fifth stage
+def test_layer0_stream_kernel_keeps_its_raw_prefetch_counted_and_its_step_loops_free_of_scratch(stats, form):
     """layer0_stream_kernel (round 5): 16 waves at 128 VGPRs -- the handful of spilled dwords are stage set-up values, written and read outside
     the step loops (an A fragment reloaded from scratch per row was the first asm-pipelined build's mistake); S1's raw rows are issued RD / 2 .. RD
     steps before they are converted, so the compiler's waits inside its step group are COUNTED (vmcnt(4..12)) apart from the one at the group's
     end where the rows change registers -- a vmcnt(0) per step there made every step wait for an HBM round trip."""
-    st = _find(stats, "layer0_stream_kernel")
-    assert st["scratch"] <= 4, f"{st['scratch']} scratch ops"
+    st = _find(stats, f"layer0_stream_kernel<{form}>")
+    assert st["scratch"] <= 6, f"{st['scratch']} scratch ops"   # one dword, stored once and reloaded in the stages' preheaders
     assert st["glds"] == 0
     inner = [w for w in st["waits"] if w[1] >= 1]
     drains = [w for w in inner if "vmcnt(0)" in w[2]]
