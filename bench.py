@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="CUs of the batch the C oracle evaluates (default: whole batch when the host has >= 64 cores)")
     ap.add_argument("--weight-seed", type=int, default=10, help="seed of the synthetic weight set (10 = the BASELINE workload; 13 / 24 land in the hi+lo-weights tier)")
     ap.add_argument("--weights-blob", default="", help="an MLTW file instead of the seeded set (e.g. tools/train_synth_weights.py's trained family): another WORKLOAD, never the driver's line")
-    ap.add_argument("--flags", type=int, default=0, help="mlt_config.flags; 0 = the shipped configuration (calibrated arithmetic + flat-content guard + decision guard, what the encoder runs); "
+    ap.add_argument("--flags", type=lambda s: int(s, 0), default=0, help="mlt_config.flags; 0 = the shipped configuration (calibrated arithmetic + flat-content guard + decision guard, what the encoder runs); "
                          "1 = exact arithmetic for 128, 2 = fast arithmetic for 64/32/16, 0x20 = without the decision guard (measurement only)")
     ap.add_argument("--sustain-s", type=float, default=8.0,
                     help="seconds of back-to-back steps AFTER the timed region for derived.sustained_cu_per_s (the 50-step region lasts 0.25 s on a cool chip; "

@@ -35,7 +35,11 @@ for f in sorted(glob.glob(os.path.join(P, f"{tag}_bench_*.json"))):
     name = os.path.basename(f)[len(tag) + 7:-5]
     if name in ("line",):
         continue
-    x = line("bench_" + name)
+    try:
+        x = line("bench_" + name)
+    except (IndexError, OSError):
+        print(f"{name:24s} (no JSON line)")
+        continue
     a = x["config"]["arithmetic"]
     extra = f" cpu {x['cpu_baseline']['value']:.0f}" if x.get("cpu_baseline") else ""
     print(f"{name:24s} {x['value'] / 1e3:8.0f} k  {x['ms_per_step']:7.3f} ms  err {x['parity']['max_abs_dlogit']:.1e}  reruns {a['guard_reruns_per_step']:6.1f}  {x['dtype'][:90]}{extra}")
@@ -69,12 +73,15 @@ if "--markdown" in sys.argv:
     lat = {l.split()[1]: float(l.split()[4]) for l in open(os.path.join(P, f"{tag}_latency_modes.txt")) if l.startswith("tier")}
     seeds = {n: b(f"seed{n}") for n in (11, 12, 13, 21, 22, 23, 24)}
     sz = {n: b(f"s{n}") for n in (64, 32, 16)}
-    nat, flat, dg, ex = b("natural"), b("flat25"), b("decision_guard"), b("exact")
+    nat, flat, ex = b("natural"), b("flat25"), b("exact")
+    dg = b("no_decision_guard") if os.path.exists(os.path.join(P, f"{tag}_bench_no_decision_guard.json")) else b("decision_guard")  # (round 5: the guard is the default; the extra leg is the run WITHOUT it)
     rows_cpu = {str(x.get("batch"))[:4]: x["value"] for x in cb["rows"]}
     print(f"| **CU-inferences/s, batch 4096 x 128x128**, seed 10 | **{d['value'] / 1e3:.0f} k** ({d['ms_per_step']:.2f} ms per batch); {dv['model_tflops']:.0f} TFLOP/s over the whole net = {dv['mfma_frac_whole_net']:.2f} of 2.5 PFLOP/s |")
     print(f"| parity over the whole timed batch | max |dlogit| {d['parity']['max_abs_dlogit']:.1e}; {d['parity']['split_mismatch_decisive']} split mismatches; {d['parity']['non_decisive']} CUs below the decidable margin |")
     print(f"| roofline kernel {r['kernel']} | {r['avg_launch_ms']:.3f} ms (HIP events; rocprofv3 batch launches {batch_ms:.3f} ms) = {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f}; SQ_VALU_MFMA_BUSY {100 * float(sq.get('mfma_util', 0)):.1f} %, bank conflicts {100 * float(sq.get('lds_conflict_frac', 0)):.1f} %; PMC traffic {next(v['hbm_bytes_per_launch'] for n, v in json.load(open(os.path.join(P, f'{tag}_pmc_traffic.json'))).items() if n.startswith('stage_128')) / 1e9:.2f} GB vs {r['algo_bytes_per_launch'] / 1e9:.2f} GB |")
-    print(f"| other launches | layer0.0 {ms('stem+block'):.3f} ({rf('stem+block'):.2f}) . layer0.1 {ms('block_s1'):.3f} ({rf('block_s1'):.2f}) . 32->64 s2 {ms('conv3x3_s2_32to64'):.3f} ({rf('conv3x3_s2_32to64'):.2f}) . 64 chain {ms('chain3_s1_64'):.3f} ({rf('chain3_s1_64'):.2f}) . layer3 {ms('stage_256'):.3f} ({rf('stage_256'):.2f}) . heads {ms('heads'):.3f} . guard select {ms('guard_select'):.3f} |")
+    front = (f"layer0 + layer1.0.conv1 streamed {ms('layer0_stream'):.3f} ({rf('layer0_stream'):.2f})" if any(n.startswith("layer0_stream") for n in km) else
+             f"layer0.0 {ms('stem+block'):.3f} ({rf('stem+block'):.2f}) . layer0.1 {ms('block_s1'):.3f} ({rf('block_s1'):.2f}) . 32->64 s2 {ms('conv3x3_s2_32to64'):.3f} ({rf('conv3x3_s2_32to64'):.2f})")
+    print(f"| other launches | {front} . 64 chain {ms('chain3_s1_64'):.3f} ({rf('chain3_s1_64'):.2f}) . layer3 {ms('stage_256'):.3f} ({rf('stage_256'):.2f}) . heads {ms('heads'):.3f} . guard select {ms('guard_select'):.3f} |")
     print(f"| whole path | {dv['whole_path']['t_bound_ms']:.3f} / {dv['whole_path']['t_measured_ms']:.3f} = {dv['whole_path']['frac']:.2f}; HBM layer-wise fraction {dv['hbm_layerwise_roofline_frac']:.2f} |")
     print(f"| decision guard | {dg['value'] / 1e3:.0f} k |")
     print("| other weight sets | " + " . ".join(f"{n}: {seeds[n]['value'] / 1e3:.0f} k ({seeds[n]['parity']['max_abs_dlogit']:.1e})" for n in (23, 11, 13, 24, 21, 22, 12)) + f" . exact: {ex['value'] / 1e3:.0f} k |")
