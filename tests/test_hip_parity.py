@@ -1096,3 +1096,27 @@ def test_layer0_stream_is_bit_identical(gpu):
         assert np.array_equal(l1, l[a:b]) and np.array_equal(s1, s[a:b]), f"streaming layer0 differs from the tiled form in CUs {a}..{b}"
     assert m.arithmetic(128)["guard_reruns"] >= 1
     m.close()
+
+
+@pytest.mark.parametrize("seed", [23, 13, 24, 11])
+def test_layer0_stream_under_the_other_tiers(gpu, seed):
+    """The streaming launch also serves the tiers that keep layer0 on the single pass: seed 23 (single pass, another rounding realisation: five
+    stages), seed 24 (hi+lo weights from layer2 on: five stages), seeds 13 / 11 (hi+lo weights in layer1's stride-2 conv / in all of layer1: the
+    fifth stage must stay out, layer0's output goes to HBM for the two-plane kernels).  320 CUs at once against the same CUs in sub-batches of
+    80 (tiled launches): bit for bit; and the batch against the oracle."""
+    import oracle
+    pkg = gpu
+    n = 320
+    blob = pkg.weights.synthetic_blob(0, seed)
+    org, pred = pkg.synth.make_patches_bulk(128, n, 6060 + seed)
+    poc, qp = pkg.synth.make_scalars(n, 6060 + seed)
+    m = _ctx(pkg, 128, blob)
+    a = m.arithmetic(128)
+    assert a["exact"] in (0, 3) and not (a["w2_units"] & 3), f"seed {seed}: layer0 is expected on the single pass, got {a}"
+    s, l = m.predict_batch(org, pred, poc, qp)
+    for lo in range(0, n, 80):
+        s1, l1 = m.predict_batch(org[lo:lo + 80], pred[lo:lo + 80], poc[lo:lo + 80], qp[lo:lo + 80])
+        assert np.array_equal(l1, l[lo:lo + 80]) and np.array_equal(s1, s[lo:lo + 80]), f"seed {seed}: streaming layer0 differs from the tiled form in CUs {lo}.."
+    ref, ref_split = oracle.Oracle(blob).forward(org[:64], pred[:64], poc[:64], qp[:64], threads=8)
+    assert np.abs(l[:64] - ref).max() <= LOGIT_TOL
+    m.close()
