@@ -87,3 +87,17 @@ int main(int argc, char **argv) {
             assert bool(got) == want, (mask, chType, intra, w, h, x, y)
             positives += want
         assert positives > 0
+
+
+def test_traffic_json_names_are_the_profile_names_of_the_runtime():
+    """scripts/make_traffic_json.py keys the PMC traffic by the launch names the runtime profiles under (bench.py looks `name@batch` up); a name the
+    runtime truncates (mlt_profile_entry.name holds 47 characters) or renames silently turns `roofline.traffic` into null.  Every fused-launch name
+    the script emits must be what mlt_api.cpp passes to prof_begin, cut to 47 characters."""
+    import re
+    src = open(os.path.join(ROOT, "fastintercu-vvc_amd", "csrc", "mlt_api.cpp")).read()
+    runtime = {m[:47] for m in re.findall(r'prof_begin\("([^"]+)"', src)}
+    script = open(os.path.join(ROOT, "scripts", "make_traffic_json.py")).read()
+    emitted = set(re.findall(r'(?:name = |else )"([^"]+)"(\[:47\])?', script))
+    fused = {(n[:47] if cut else n) for n, cut in emitted if n.startswith(("layer0_stream", "heads"))}
+    assert len(fused) == 3
+    assert fused and fused <= runtime, (fused - runtime, sorted(runtime)[:12])
