@@ -557,6 +557,25 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   return MLT_OK;
 }
 
+// The three stride-1 convs of layer1 (64 channels at 32 x 32) as ONE streaming launch (layer1_stream_kernel): bit-identical to run_chain3's
+// 64-channel chain, weights resident in registers, b0 never in HBM.  t NHWC, sc chunk-major (what layer0_stream_kernel<true> / the stride-2 launch write).
+int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, const void *t, const void *sc, void *y, float *gap, bool y_c16) {
+  Layer1Args a{};
+  a.t = t; a.sc = sc; a.y = y; a.y_c16 = y_c16 ? 1 : 0; a.gap = gap; a.gap_slots = gap_slots(32 * 32); a.n = n;
+  const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
+  for (int k = 0; k < 3; ++k) { a.w[k] = pcs[k]->d_w; a.bias[k] = pcs[k]->d_bias; a.scale[k] = pcs[k]->acc_scale; }
+  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP1"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int grid_x = n > wg_cap ? wg_cap : n;
+  const double px = (double)n * 32 * 32;
+  Launch L{ctx};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = L.prof_begin("layer1_stream_h32(conv2+conv1+conv2)", 3.0 * 2.0 * px * 64 * 64 * 9, px * 64 * 2 * 3 + 3.0 * 72 * 1024, e0, e1);
+  if (rc) return rc;
+  HIP_TRY(ctx, mlt_launch_layer1_stream(a, grid_x, ctx->stream));
+  if ((rc = L.prof_end(e1))) return rc;
+  return debug_dump(ctx, "chain3_s1_64_h32(conv2+conv1+conv2)", y, (size_t)px * 64 * 2);
+}
+
 // the network in the size's main arithmetic: `model` (fast, or exact when that is the configured / calibrated arithmetic), or -- middle
 // tier -- `model_w2` (hi+lo WEIGHTS on the fast tiling: the W2 forms of the fused kernels)
 // d_flat != NULL: also produce the flat-content guard's per-CU statistic (fused into the first kernel where that kernel reads
@@ -692,6 +711,13 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
+        // round 5: batches of >= 256 CUs run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain)
+        static const int l1_min = [] { const char *e = tuning_env("MLT_L1_STREAM_MIN"); return tuning_env("MLT_NO_L1_STREAM") ? 0 : e ? std::atoi(e) : 256; }();
+        const mlt::PackedConv &q2 = B0c.conv2;
+        if (s == 1 && !chain_s2 && m.planes[s] == 64 && hout == 32 && io.ysc_c16 && !mt.w2 && !mt.exact && l1_min > 0 && n >= l1_min &&
+            q2.taps == 9 && q2.kc == 64 && q2.ct == 64 && outs[s] && !last) {
+          if ((rc = run_layer1_stream(ctx, B0c, mt.blocks[s][1], n, pool[0], pool[1], outs[s], gaps[s], out_c16))) return rc;
+        } else
         if ((rc = run_chain3(ctx, B0c, mt.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
                              cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
         cur = outs[s];

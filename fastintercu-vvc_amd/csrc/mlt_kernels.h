@@ -116,6 +116,21 @@ struct Layer0Args {
   float scale5;
 };
 
+// The three stride-1 convs of layer1 (64 channels at 32 x 32) as a streaming pipeline (layer1_stream_kernel, round 5): chain_kernel<64>'s
+// arithmetic, weights resident in registers, rows through LDS rings, b0 never in HBM.
+#define MLT_L1_LDS_BYTES 158240  /* rings of 4 / 8 / 4 map rows + zero row (34 px x 144 B), 2 sc rows, 16 accumulator hand-over blocks of 4 KiB, biases */
+struct Layer1Args {
+  const void *t;               // [n][32][32][64] fp16 NHWC: relu(bn1(conv1 x)) of layer1.0
+  const void *sc;              // the projection shortcut, chunk-major [n][4][1024][16] fp16 (ConvArgs.ysc_c16)
+  const void *w[3];            // layer1.0.conv2, layer1.1.conv1, layer1.1.conv2: packed fp16 (ct 64, kc 64: 72 KiB each)
+  const float *bias[3];
+  float scale[3];
+  void *y;                     // stage output [n][32][32][64] fp16, NHWC or chunk-major (y_c16)
+  int y_c16;
+  float *gap;                  // fp32 GAP partial sums [n][gap_slots][64]
+  int gap_slots, n;
+};
+
 // Fused chain of stride-1 3x3 convs on whole samples (chain_kernel): the BasicBlock tail of a stage,
 //   b0 = relu(bn2(conv2(t)) + sc) ; t1 = relu(bn1(conv1(b0))) ; out = relu(bn2(conv2(t1)) + b0)      (arch:52-57)
 // with every intermediate kept on chip (activations in LDS, b0 as the residual in registers).
@@ -220,4 +235,5 @@ hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds,
 hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st);     // w2: hi+lo weights (8 x 32 tiles)
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st);
 hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x, hipStream_t st);
+hipError_t mlt_launch_layer1_stream(const Layer1Args &a, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

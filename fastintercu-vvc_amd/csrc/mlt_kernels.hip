@@ -278,6 +278,7 @@ template <int Q> __device__ __forceinline__ half4 act_quad(const float16v &A, fl
 #include "mlt_chain_kernel.inc"   // chain_kernel (+ KARG)
 #include "mlt_front_kernels.inc"  // block32_kernel, stem5_kernel, stem_block_kernel
 #include "mlt_layer0_kernel.inc"  // layer0_stream_kernel
+#include "mlt_layer1_kernel.inc"  // layer1_stream_kernel
 #include "mlt_tail_kernels.inc"   // heads_kernel, flat_stat / guard kernels
 
 // ---------------------------------------------------------------------------------------------
@@ -798,6 +799,13 @@ hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x,
   }
   if (hipError_t e = ensure_big_lds(layer0_stream_kernel<false>, once[0]); e != hipSuccess) return e;
   hipLaunchKernelGGL(layer0_stream_kernel<false>, dim3(grid_x), dim3(1024), MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot: 4 stages x 4 row units
+  return hipGetLastError();
+}
+
+hipError_t mlt_launch_layer1_stream(const Layer1Args &a, int grid_x, hipStream_t st) {
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(layer1_stream_kernel, once); e != hipSuccess) return e;
+  hipLaunchKernelGGL(layer1_stream_kernel, dim3(grid_x), dim3(1024), MLT_L1_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

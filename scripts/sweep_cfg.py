@@ -22,10 +22,12 @@ VARIANTS = {  # name -> -D defines (the CFG_* knobs in csrc/mlt_kernels.hip); ru
     # (profiles/r05o_l0_sweep2.txt: wave priorities by stage 0.910 / 0.908 / 0.887, no cross-barrier prefetch 0.879 against 0.894 -- all noise)
     # (a second accumulator for the odd items, to see whether the dependent MFMA chain limits a wave, spilled 24 VGPRs at 128; scripts/probes/mfma_chain_probe.hip
     #  answers the question in isolation: it does not -- one wave with one chain already runs the pipe at the register-only rate)
-    # the five-stage form (layer0_stream_kernel<true>): cross-barrier prefetch off, raw rows 2 / 6 steps per group
-    "l0f_noxpre": ["CFG_L0_XPRE=0"],
-    "l0f_rd2": ["CFG_L0_RD=2"],
-    "l0f_rd6": ["CFG_L0_RD=6"],
+    # (the five-stage form's knobs -- cross-barrier prefetch, raw-row group -- all within noise: profiles/r05o_l0_sweeps.txt)
+    # layer1_stream_kernel: fragment depth, knock-outs (1 no epilogue waves, 2 no accumulator hand-over, 4 loaders idle)
+    "l1_pd6": ["CFG_L1_PD=6"],
+    "l1_ko1": ["CFG_L1_KO=1"],
+    "l1_ko2": ["CFG_L1_KO=2"],
+    "l1_ko4": ["CFG_L1_KO=4"],
 }
 # round 3, 32->64 stride-2 kernel (0.446 ms): all slower -- 256-pixel tiles on 16 waves 0.81, 64 couts per wave 0.94, both 0.54, UN 6 0.46
 #   "s2_wp8": ["CFG_3264_WP=8"], "s2_wcb2_wp8": ["CFG_3264_WCB=2", "CFG_3264_WC=1", "CFG_3264_WP=8"]
