@@ -54,7 +54,7 @@ for d in sorted(glob.glob(os.path.join(run, "pmc", "*/"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0)):
         k = r["Kernel_Name"]
-        if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k or "layer0_" in k:
+        if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k or "layer0_" in k or "layer1_" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, x in v.items():

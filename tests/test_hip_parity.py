@@ -1076,7 +1076,8 @@ def test_exact_lite_arithmetic_against_the_oracle(gpu):
 
 
 def test_layer0_stream_is_bit_identical(gpu):
-    """Round 5: batches of >= 256 CUs of 128 x 128 run ALL of layer0 in one streaming launch (layer0_stream_kernel: four row stages handing rows to
+    """(Also covers layer1_stream_kernel, the 64-channel stage's streaming launch, which switches on at the same batch size.)
+    Round 5: batches of >= 256 CUs of 128 x 128 run ALL of layer0 in one streaming launch (layer0_stream_kernel: four row stages handing rows to
     each other through LDS rings, b0 never in HBM); smaller batches keep the two tiled launches (stem_block_kernel -> block32_kernel).  Same
     arithmetic in the same order: the logits must agree bit for bit -- 301 CUs (workgroups with one CU and with two; pipeline fill and drain across
     the CU boundary) against the same CUs in sub-batches of 100, flat CUs included (the guard statistic is gathered by the streaming kernel too)."""

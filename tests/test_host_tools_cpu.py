@@ -98,6 +98,6 @@ def test_traffic_json_names_are_the_profile_names_of_the_runtime():
     runtime = {m[:47] for m in re.findall(r'prof_begin\("([^"]+)"', src)}
     script = open(os.path.join(ROOT, "scripts", "make_traffic_json.py")).read()
     emitted = set(re.findall(r'(?:name = |else )"([^"]+)"(\[:47\])?', script))
-    fused = {(n[:47] if cut else n) for n, cut in emitted if n.startswith(("layer0_stream", "heads"))}
-    assert len(fused) == 3
+    fused = {(n[:47] if cut else n) for n, cut in emitted if n.startswith(("layer0_stream", "layer1_stream", "heads"))}
+    assert len(fused) == 4
     assert fused and fused <= runtime, (fused - runtime, sorted(runtime)[:12])

@@ -104,3 +104,12 @@ def test_layer0_stream_kernel_keeps_its_raw_prefetch_counted_and_its_step_loops_
     counted = [w for w in pool if re.search(r"vmcnt\((\d+)\)", w[2]) and int(re.search(r"vmcnt\((\d+)\)", w[2]).group(1)) >= 4]
     assert len(drains) <= 2, f"compiler drains inside loops: {drains}"          # the LDS-clearing loop's neighbourhood at the top + the end of S1's step group
     assert len(counted) >= 4, f"S1's raw-row waits are no longer counted: {inner}"
+
+
+def test_layer1_stream_kernel_fits_its_waves_without_scratch(stats):
+    """layer1_stream_kernel (round 5): twelve conv waves with 18 resident A fragments each, at 128 VGPRs -- no spills (a reload in a row loop is a
+    vector-memory round trip per row), and its loader waves' waits are counted."""
+    st = _find(stats, "layer1_stream_kernel")
+    assert st["scratch"] == 0, f"{st['scratch']} scratch ops"
+    drains = [w for w in st["waits"] if w[1] >= 1 and "vmcnt(0)" in w[2]]
+    assert len(drains) <= 3, f"compiler drains inside loops: {drains}"   # two beside the LDS-clearing loop at the top, one at the end of the loaders' step group
