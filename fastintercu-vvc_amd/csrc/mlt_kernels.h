@@ -118,7 +118,7 @@ struct Layer0Args {
 
 // The three stride-1 convs of layer1 (64 channels at 32 x 32) as a streaming pipeline (layer1_stream_kernel, round 5): chain_kernel<64>'s
 // arithmetic, weights resident in registers, rows through LDS rings, b0 never in HBM.
-#define MLT_L1_LDS_BYTES 158240  /* rings of 4 / 8 / 4 map rows + zero row (34 px x 144 B), 2 sc rows, 16 accumulator hand-over blocks of 4 KiB, biases */
+#define MLT_L1_LDS_BYTES 159008  /* rings of 4 / 8 / 4 map rows + zero row (34 px x 144 B), 2 sc rows, 16 accumulator hand-over blocks of 4 KiB, biases */
 struct Layer1Args {
   const void *t;               // [n][32][32][64] fp16 NHWC: relu(bn1(conv1 x)) of layer1.0
   const void *sc;              // the projection shortcut, chunk-major [n][4][1024][16] fp16 (ConvArgs.ysc_c16)

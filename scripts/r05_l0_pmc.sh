@@ -18,7 +18,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc", "*/"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0)):
         k = r["Kernel_Name"]
-        if "layer0" in k or "block32" in k or "stem_block" in k or "chain_kernel<128" in k:
+        if "layer0" in k or "layer1" in k or "block32" in k or "stem_block" in k or "chain_kernel<128" in k:
             acc[k[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, x in v.items():
