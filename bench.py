@@ -90,15 +90,10 @@ def launch_ranks(args):
 
 
 def source_signature():
-    """sha256 over the kernel + runtime sources (every file of csrc/, sorted): profiles/pmc_traffic.json is only valid for the build it was measured on."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "fastintercu-vvc_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".inc", ".cpp", ".h")):
-            h.update(f.encode())
-            with open(os.path.join(csrc, f), "rb") as fh:
-                h.update(fh.read())
-    return h.hexdigest()[:16]
+    """sha256 over the kernel + runtime sources (every file of csrc/, sorted): profiles/pmc_traffic.json is only valid for the build it was
+    measured on.  One definition, in the package's build recipe -- the library carries the same value (mlt_build_signature)."""
+    import mltcnn_pkg
+    return mltcnn_pkg.load().build.source_signature()
 
 
 def main():

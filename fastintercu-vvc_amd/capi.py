@@ -24,7 +24,7 @@ FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (mea
 FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
 FLAG_EXACT_LITE = 0x40  # round 5 (measurement): exact-configured sizes run the exact-lite arithmetic (FP8 cross terms)
 FLAG_NO_DECISION_GUARD = 0x20  # ABI 4: no exact re-evaluation of CUs with a near-tie on the decision head (measurement only)
-EXPORTS = ["mlt_abi_version", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_calibrate", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
+EXPORTS = ["mlt_abi_version", "mlt_build_signature", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_calibrate", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
            "mlt_num_logits", "mlt_profile_enable", "mlt_profile_read", "mlt_last_error", "mlt_shutdown"]
 
@@ -76,6 +76,12 @@ def load_library():
     lib = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int
     lib.mlt_abi_version.restype = i32
+    lib.mlt_build_signature.restype = C.c_char_p
+    if "MLT_LIB_PATH" not in os.environ and os.path.isdir(_build.CSRC):
+        # the binary travels to the GPU box with the snapshot: one built from other sources than the tree's must not pass for them
+        have, want = lib.mlt_build_signature().decode(), _build.source_signature()
+        if have != want:
+            raise RuntimeError(f"{path} was built from sources {have}, the tree is {want}: rebuild (python __graft_entry__.py)")
     lib.mlt_init.argtypes = [C.POINTER(MltConfig), C.POINTER(vp)]
     lib.mlt_num_devices.argtypes = [vp]
     lib.mlt_device_ctx.argtypes = [vp, i32]

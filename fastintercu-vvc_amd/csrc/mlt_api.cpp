@@ -1070,10 +1070,24 @@ struct CalibSession {
     HIP_TRY(ctx, hipMemcpy(out.data(), d_lg, out.size() * 4, hipMemcpyDeviceToHost));
     return MLT_OK;
   }
+  // MLT_CALIB_REPLACE needs enough of the caller's CUs to carry the statistical admission rule on their own (it assumes thousands of logits:
+  // the synthetic set has 560 CUs): when fewer than kCalibMinReplace of them are left after dropping those the flat-content guard re-evaluates
+  // exactly anyway -- all of them flat, or a tiny n -- the synthetic set is kept and the caller's CUs are APPENDED to it instead (visible to the
+  // caller as mlt_arith_info.calib_cus > calib_caller_cus).  No tier is ever admitted on an empty or near-empty set.
+  static constexpr int kCalibMinReplace = 256;
   int begin() {
+    int rc = stage_set(extra && extra->replace);
+    if (rc == MLT_OK && extra && extra->replace && n_used < kCalibMinReplace) {
+      (void)hipFree(d);
+      d = nullptr;
+      rc = stage_set(false);
+    }
+    return rc ? rc : run(le, true, 0);
+  }
+  int stage_set(bool replace) {
     const int S = st.size, nl = st.model.n_logits;
     const size_t cs = (size_t)S * S;
-    const CalibInputs *syn = (extra && extra->replace) ? nullptr : &calibration_set(S);
+    const CalibInputs *syn = replace ? nullptr : &calibration_set(S);
     n_syn = syn ? kCalibN : 0;
     const int n_ex = extra ? extra->n : 0;
     n = n_syn + n_ex;
@@ -1113,7 +1127,7 @@ struct CalibSession {
     }
     n_used = 0; n_caller_used = 0;
     for (int i = 0; i < n; ++i) { n_used += use[(size_t)i]; if (i >= n_syn) n_caller_used += use[(size_t)i]; }
-    return run(le, true, 0);
+    return MLT_OK;
   }
   int price(unsigned mask, unsigned xmask = 0, mlt::Model *whole = nullptr) {
     int rc = run(lf, false, mask, xmask, whole);
@@ -1350,6 +1364,14 @@ extern "C" {
 
 int mlt_abi_version(void) { return MLT_ABI_VERSION; }
 
+// Signature of the sources this binary was built from (fastintercu-vvc_amd/build.py passes -DMLT_SOURCE_SIG; the marker is also what build.py's
+// stale() greps the file for): the host side refuses a library that does not match the csrc/ beside it.
+#ifndef MLT_SOURCE_SIG
+#define MLT_SOURCE_SIG "unsigned-build!!"
+#endif
+static const char g_source_sig[] = "MLTCNN_SOURCE_SIG=" MLT_SOURCE_SIG;
+const char *mlt_build_signature(void) { return g_source_sig + sizeof("MLTCNN_SOURCE_SIG=") - 1; }
+
 int mlt_num_logits(int size) { return size == 128 ? 9 : (size == 64 || size == 32 || size == 16) ? 15 : 0; }
 
 const char *mlt_last_error(const mlt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
@@ -1378,6 +1400,21 @@ int mlt_calibrate(mlt_ctx *ctx, int size, const int16_t *org, const int16_t *pre
   rc = load_all(ctx, size, keep.data(), keep.size(), &ex);
   if (rc == MLT_OK) ctx->sz[size_index(size)].blob = std::move(keep);
   return rc;
+}
+
+// Host-only hook (not part of include/mltcnn.h; no HIP call): the synthetic calibration set of a CU size, so that the numerics tools
+// (tools/attribute_error.py, scripts/emul_fast.py) and the CPU tests see exactly the CUs the load-time calibration prices.  Buffers: dense
+// [560][size][size] int16 org / pred, int32 poc / qp / content class; any of them may be NULL.  Returns the number of CUs (560) or -1.
+int mlt_calibration_set_copy(int size, int16_t *org, int16_t *pred, int32_t *poc, int32_t *qp, int32_t *cls) {
+  if (size_index(size) < 0) return -1;
+  const CalibInputs &ci = calibration_set(size);
+  const size_t cs = (size_t)size * size * kCalibN;
+  if (org) std::memcpy(org, ci.org.data(), cs * 2);
+  if (pred) std::memcpy(pred, ci.pred.data(), cs * 2);
+  if (poc) std::memcpy(poc, ci.poc.data(), (size_t)kCalibN * 4);
+  if (qp) std::memcpy(qp, ci.qp.data(), (size_t)kCalibN * 4);
+  if (cls) for (int i = 0; i < kCalibN; ++i) cls[i] = ci.cls[(size_t)i];
+  return kCalibN;
 }
 
 // CPU test hook of the tier search (mlt_tier_search.h; not part of include/mltcnn.h): no HIP call on this path

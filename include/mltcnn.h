@@ -169,7 +169,9 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
  * (HOST memory, dense [n][size][size] int16 org / pred as in mlt_predict_batch, int32 poc / qp; e.g. what host/mlt_split_predictor.hpp's call
  * dump recorded from real sequences: tools/calibrate_from_dump.py) APPENDED to the synthetic set (their own content class: the worst pooled
  * rms over classes counts) or REPLACING it.  Caller CUs the flat-content guard re-evaluates exactly anyway are left out of the statistics
- * (mlt_arith_info.calib_caller_cus = those that counted).  1 <= n <= 4096.  The size must have been loaded with mlt_load_weights / weights_dir
+ * (mlt_arith_info.calib_caller_cus = those that counted).  MLT_CALIB_REPLACE with fewer than 256 CUs that count (a tiny n, or content the
+ * flat guard takes anyway) cannot carry the statistical admission rule: the call then behaves like MLT_CALIB_APPEND (the synthetic set stays;
+ * mlt_arith_info.calib_cus > calib_caller_cus tells) -- no arithmetic is ever admitted on an empty or near-empty set.  1 <= n <= 4096.  The size must have been loaded with mlt_load_weights / weights_dir
  * (the library keeps the blob); sizes configured exact (MLT_FLAG_EXACT_128) or loaded with MLT_FLAG_NO_CALIBRATION are left alone.  Every
  * device of a multi-device context is re-calibrated; like a reload it invalidates captured graphs, and the outcome is read with
  * mlt_arithmetic.  On failure the size is unloaded (the caller keeps -1 / full RDO until it loads weights again). */
@@ -242,6 +244,9 @@ int mlt_profile_read(mlt_ctx *ctx, mlt_kernel_time *out, int cap);
 
 const char *mlt_last_error(const mlt_ctx *ctx); /* ctx may be NULL: last init error */
 int mlt_abi_version(void);
+/* 16 hex digits: sha256 over the sources (fastintercu-vvc_amd/csrc/, sorted by name) this binary was built from -- what bench.py reports as
+ * derived.source_sig and what the Python host side checks against the tree before it uses the library ("unsigned-build!!" for a build outside build.py). */
+const char *mlt_build_signature(void);
 
 /* Release everything (natural home: EncCu::destroy, EncCu.cpp:160-206). NULL is allowed. */
 void mlt_shutdown(mlt_ctx *ctx);

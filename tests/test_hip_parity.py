@@ -978,7 +978,7 @@ def test_calibrate_on_caller_content(gpu):
     entry point, the oracle within the tolerance); argument errors are errors."""
     from oracle import Oracle
     pkg = gpu
-    size, n = 128, 192
+    size, n = 128, 320
     blob = pkg.weights.synthetic_blob(0, 10)
     org, pred, _ = pkg.synth.make_mix_bulk(size, n, 0xCA11B, 0.0, True)       # 1/f-spectrum scenes + motion-shifted prediction
     org[:8] = 400; pred[:8] = 404                                             # constant CUs: flagged by the flat guard, must not count
@@ -1004,11 +1004,17 @@ def test_calibrate_on_caller_content(gpu):
     m.calibrate(size, org, pred, poc, qp, replace=True)
     a2 = m.arithmetic(size)
     print("replace:", a2)
-    assert a2["calib_cus"] == a2["calib_caller_cus"] == a1["calib_caller_cus"]
-    # a caller whose content is ALL caught by the flat guard decides nothing: no CU counts, the single pass stays (those CUs run exact anyway)
+    assert a2["calib_cus"] == a2["calib_caller_cus"] == a1["calib_caller_cus"] >= 256
+    # REPLACE needs >= 256 CUs that count: a caller whose content is ALL caught by the flat guard, or a handful of CUs, cannot carry
+    # the admission rule -- the synthetic set stays and the call is an APPEND; no tier is ever admitted on an empty set
     m.calibrate(size, org[:8], pred[:8], poc[:8], qp[:8], replace=True)
     a3 = m.arithmetic(size)
-    assert a3["calib_cus"] == 0 and a3["exact"] == 0 and a3["calib_max"] == 0.0
+    print("replace, all flat:", a3)
+    assert a3["calib_cus"] == 560 and a3["calib_caller_cus"] == 0 and a3["calib_max"] > 0.0
+    assert (a3["exact"], a3["w2_units"], a3["x_units"], a3["rounding"]) == (a0["exact"], a0["w2_units"], a0["x_units"], a0["rounding"])
+    m.calibrate(size, org[8:108], pred[8:108], poc[8:108], qp[8:108], replace=True)
+    a4 = m.arithmetic(size)
+    assert a4["calib_caller_cus"] > 0 and a4["calib_cus"] == 560 + a4["calib_caller_cus"]
     # a tolerance no tier below it meets: the caller's CUs take the size to the exact arithmetic like the synthetic ones do
     t = _ctx(pkg, size, blob, tolerance=2e-5)
     t.calibrate(size, org, pred, poc, qp, replace=True)
