@@ -23,6 +23,7 @@ FLAG_DECISION_GUARD = 0x4  # ABI <= 3 opt-in; since ABI 4 the decision guard is 
 FLAG_NO_FLAT_GUARD = 0x8   # fast arithmetic without the flat-content guard (measurement only)
 FLAG_NO_CALIBRATION = 0x10  # keep the fast arithmetic whatever the weight set (measurement only)
 FLAG_EXACT_LITE = 0x40  # round 5 (measurement): exact-configured sizes run the exact-lite arithmetic (FP8 cross terms)
+FLAG_NO_MAGNITUDE_GUARD = 0x80  # round 6 (measurement): never admit a tier behind the magnitude guard
 FLAG_NO_DECISION_GUARD = 0x20  # ABI 4: no exact re-evaluation of CUs with a near-tie on the decision head (measurement only)
 EXPORTS = ["mlt_abi_version", "mlt_build_signature", "mlt_init", "mlt_num_devices", "mlt_device_ctx", "mlt_load_weights", "mlt_calibrate", "mlt_arithmetic", "mlt_predict", "mlt_predict_batch",
            "mlt_predict_batch_device", "mlt_submit", "mlt_flush", "mlt_wait", "mlt_synchronize", "mlt_set_stream", "mlt_alloc_pinned", "mlt_free_pinned",
@@ -40,7 +41,7 @@ class MltArithInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
                 ("flat_guard", C.c_int32), ("decision_guard", C.c_int32), ("guard_reruns", C.c_uint64),
                 ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("rounding", C.c_int32),
-                ("calib_cus", C.c_int32), ("calib_caller_cus", C.c_int32)]
+                ("calib_cus", C.c_int32), ("calib_caller_cus", C.c_int32), ("mag_guard_thr", C.c_float), ("mag_guard_flagged", C.c_float)]
 
 
 class MltKernelTime(C.Structure):

@@ -188,6 +188,11 @@ struct HeadArgs {
   int32_t *g_count, *g_idx, *g_flat;
   int g_flat_thr, g_near_thr;
   float g_margin;
+  // Round 6, the MAGNITUDE guard (mlt_api.cpp: SizeState.mag_thr): mag[n] <- max over all logits of sum_k |w_ck feat_k| -- the size of the
+  // feature-driven part of the logits, which is what the fp16 pipeline's RELATIVE error acts on (poc, qp and the bias enter exactly).  NULL: not
+  // wanted.  g_mag_thr > 0 (single-CU launches): CU 0 is also flagged when its magnitude exceeds the threshold (NaN included).
+  float *mag;
+  float g_mag_thr;
 };
 
 // ---- parity guard (fast arithmetic): device-side selection of the CUs that are re-evaluated with the exact arithmetic ----
@@ -206,6 +211,8 @@ struct GuardSelectArgs {
   int flat_thr;                // select when the count of EXACTLY flat quads (flat >> MLT_FLAT_EXACT_SHIFT) >= flat_thr (flat != NULL) ...
   int near_thr;                // ... or the count of near-flat quads (flat & 0xFFFF) >= near_thr
   float margin;                // select when top1 - top2 of the decision head < margin (logits != NULL, margin > 0)
+  const float *mag;            // [n] (HeadArgs.mag) or NULL: select when mag > mag_thr (round 6: the magnitude guard)
+  float mag_thr;
 };
 struct GuardGatherArgs {
   const int16_t *org, *pred;

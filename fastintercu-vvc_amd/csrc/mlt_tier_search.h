@@ -19,6 +19,15 @@ struct TierPrice {
   float rms = 0.f;   // worst rms pooled per content class / per head
   float max = 0.f;   // largest |dlogit| over the calibration logits
   float tail = 0.f;  // max / (rms pooled over everything)
+  // Round 6 -- the same configuration behind the MAGNITUDE guard (mlt_api.cpp, "magnitude guard"): the pricer fills these when the plain
+  // figures above miss the contract and it has such a guard.  g_thr = the magnitude up to which the configuration's worst RELATIVE error
+  // (|dlogit| / magnitude, over every calibration CU) stays within max_frac x tolerance; CUs above it are re-evaluated exactly at run time, so
+  // g_rms / g_max / g_tail are the figures over the CUs at or below it -- the synthetic set's, the caller's, and a further in-distribution set
+  // (texture + 1/f scenes) that restores the sample size; g_flag = the fraction of the in-distribution CUs above the threshold (the price
+  // of the guard on ordinary content: each costs an exact re-run).
+  bool g_valid = false;
+  float g_rms = 0.f, g_max = 0.f, g_tail = 0.f, g_thr = 0.f, g_flag = 0.f;
+  TierPrice guarded() const { TierPrice p; p.rms = g_rms; p.max = g_max; p.tail = g_tail; return p; }
 };
 
 struct TierPricer {
@@ -35,9 +44,14 @@ struct TierRules {
   float k_min = 5.5f, k_max = 6.5f, k_tail = 1.1f;   // k = clamp(k_tail x tail, k_min, k_max): k x rms <= tolerance
   float max_frac = 0.65f;                            // max <= max_frac x tolerance (128 model; the small models: 0.5)
   float refine_rms_frac = 0.95f, refine_max_frac = 0.6f;   // refinements of an admitted configuration (greedy drops) are held to a stricter rule
+  float guard_flag_max = 0.05f;                      // round 6: a configuration behind the magnitude guard may send at most this fraction of the in-distribution
+                                                     // calibration CUs to the exact re-run (5 % of a batch at the exact arithmetic's rate costs ~20 % of the step)
   float k(const TierPrice &p) const { return std::min(k_max, std::max(k_min, k_tail * p.tail)); }
   bool within(const TierPrice &p) const { return k(p) * p.rms <= tolerance && p.max <= max_frac * tolerance; }
   bool within_refined(const TierPrice &p) const { return k(p) * p.rms <= refine_rms_frac * tolerance && p.max <= refine_max_frac * tolerance; }
+  // the same two rules on the figures behind the magnitude guard (same constants; the guard's threshold itself comes from max_frac x tolerance)
+  bool within_guarded(const TierPrice &p) const { return p.g_valid && p.g_thr > 0.f && p.g_flag <= guard_flag_max && within(p.guarded()); }
+  bool within_refined_guarded(const TierPrice &p) const { return p.g_valid && p.g_thr > 0.f && p.g_flag <= guard_flag_max && within_refined(p.guarded()); }
   // how far a configuration is from the line: the larger of its two admission figures, relative to their limits
   float score(const TierPrice &p) const { return std::max(k(p) * p.rms / tolerance, p.max / (max_frac * tolerance)); }
 };
@@ -50,6 +64,7 @@ struct TierForce {
   int w2_units = -1;       // MLT_W2_UNITS: exactly this unit mask in hi+lo weights
   int small_prefix = -1;   // MLT_SMALL_PREFIX: small models, exactly the prefix of k single-pass stages
   bool no_roundings = false, no_w2 = false, no_xmix = false, no_w2_units = false, no_x_units = false, no_lite = false;
+  bool no_mag_guard = false;   // MLT_NO_MAG_GUARD: never admit a configuration behind the magnitude guard (the round-5 search)
 };
 
 struct TierChoice {
@@ -58,8 +73,10 @@ struct TierChoice {
   bool w2 = false;         // a middle tier was admitted (w2_units / x_units say where)
   unsigned w2_units = 0, x_units = 0;
   int rounding = 0;        // realisation of the single-pass weights the search ended on
-  TierPrice price;         // of the chosen non-exact tier; when exact: of the single pass (128) / of the last candidate priced (small)
+  TierPrice price;         // of the chosen non-exact tier (behind the magnitude guard: the guarded figures); when exact: of the single pass (128) / of the last candidate priced (small)
   int priced = 0;          // number of price() calls
+  float mag_thr = 0.f;     // round 6: > 0 = the chosen tier was admitted behind the magnitude guard with this threshold
+  float mag_flag = 0.f;    // ... which flags this fraction of the in-distribution calibration CUs
 };
 
 inline unsigned units_of_stages(unsigned stages) {
@@ -94,13 +111,29 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
   out = TierChoice();
   int rc;
   auto price = [&](unsigned w2u, unsigned xu, int r, TierPrice &p) { ++out.priced; return pr.price(w2u, xu, r, p); };
+  // Admission: the plain rule first; failing that -- round 6 -- the same rule on the figures behind the magnitude guard (when the pricer supplies
+  // them).  Once a configuration has been admitted behind the guard, its refinements are judged behind the guard too (`guarded`), each with
+  // its own threshold; `thr` follows the configuration that is kept.
+  bool guarded = false;
+  float thr = 0.f, flag = 0.f;
+  auto admit = [&](const TierPrice &p) -> bool {
+    if (R.within(p)) { guarded = false; thr = 0.f; flag = 0.f; return true; }
+    if (!F.no_mag_guard && R.within_guarded(p)) { guarded = true; thr = p.g_thr; flag = p.g_flag; return true; }
+    return false;
+  };
+  auto admit_refined = [&](const TierPrice &p) -> bool {
+    if (!guarded) return R.within_refined(p);
+    if (R.within_refined_guarded(p)) { thr = p.g_thr; flag = p.g_flag; return true; }
+    return false;
+  };
+  auto figures = [&](const TierPrice &p) { return guarded ? p.guarded() : p; };
   TierPrice P;
   if ((rc = price(0, 0, 0, P))) return rc;
   int r = 0;
   const bool force_mask = F.w2_mask >= 0, force_x = F.x_mask >= 0, force_units = F.w2_units >= 0, force_rounding = F.rounding >= 0;
   // 1. the single pass with another REALISATION of the weights' rounding (draws of one error distribution: a set a little over the line may
   //    have one under it); none admitted -> the lower tiers are searched on the realisation that came closest
-  if ((!R.within(P) || force_rounding) && !F.no_roundings && !force_mask) {
+  if ((!admit(P) || force_rounding) && !F.no_roundings && !force_mask) {
     float best_score = R.score(P);
     int best_v = 0;
     bool got = false;
@@ -108,7 +141,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
       if (force_rounding) v = std::min(std::max(F.rounding, 0), n_roundings - 1);
       TierPrice Pv;
       if ((rc = price(0, 0, v, Pv))) return rc;
-      got = R.within(Pv) || force_rounding;
+      got = admit(Pv) || force_rounding;
       if (got) { r = v; P = Pv; }
       else if (R.score(Pv) < best_score) { best_score = R.score(Pv); best_v = v; }
       if (force_rounding) break;
@@ -120,7 +153,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
   }
   out.rounding = r;
   out.price = P;
-  if (R.within(P) && !force_mask) return 0;  // the single pass
+  if (admit(P) && !force_mask) { out.price = figures(P); out.mag_thr = thr; out.mag_flag = flag; return 0; }  // the single pass (plain, or behind the magnitude guard)
   const TierPrice P1 = P;
   bool ok = false;
   unsigned w2_mask = 0, x_mask = 0, w2u = 0, xu = 0;
@@ -130,7 +163,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
       const unsigned mask = force_mask ? ((unsigned)F.w2_mask & 0xFu) : kW2StageOrder[k];
       if (mask == 0) break;
       if ((rc = price(units_of_stages(mask), 0, r, P))) return rc;
-      if ((ok = R.within(P) || force_mask)) { w2_mask = mask; w2u = units_of_stages(mask); }  // (a forced mask is kept whatever it measures: knock-out timing builds)
+      if ((ok = admit(P) || force_mask)) { w2_mask = mask; w2u = units_of_stages(mask); }  // (a forced mask is kept whatever it measures: knock-out timing builds)
       if (force_mask) break;
     }
   }
@@ -140,7 +173,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
       const unsigned xm = force_x ? ((unsigned)F.x_mask & 0xFu) : kXStageOrder[k];
       if (xm == 0 || xm == 0xFu) break;
       if ((rc = price(units_of_stages(0xFu & ~xm), units_of_stages(xm), r, P))) return rc;
-      if ((ok = R.within(P) || force_x)) { w2_mask = 0xFu & ~xm; w2u = units_of_stages(w2_mask); x_mask = xm; xu = units_of_stages(xm); }
+      if ((ok = admit(P) || force_x)) { w2_mask = 0xFu & ~xm; w2u = units_of_stages(w2_mask); x_mask = xm; xu = units_of_stages(xm); }
       if (force_x) break;
     }
     if (ok && !force_x) {
@@ -150,7 +183,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
         if (!(w2_mask & bit)) continue;
         TierPrice Pd;
         if ((rc = price(units_of_stages(w2_mask & ~bit), xu, r, Pd))) return rc;
-        if (R.within_refined(Pd)) { w2_mask &= ~bit; kept = Pd; }
+        if (admit_refined(Pd)) { w2_mask &= ~bit; kept = Pd; }
       }
       w2u = units_of_stages(w2_mask);
       P = kept;
@@ -169,7 +202,7 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
         if (illegal_w2_unit_drop(kW2UnitDrop[k], w2u, xu)) continue;
         TierPrice Pd;
         if ((rc = price(w2u & ~bit, xu, r, Pd))) return rc;
-        if (R.within_refined(Pd)) { w2u &= ~bit; kept = Pd; }
+        if (admit_refined(Pd)) { w2u &= ~bit; kept = Pd; }
       }
       P = kept;
     }
@@ -182,12 +215,12 @@ inline int search_tier_128(TierPricer &pr, const TierRules &R, const TierForce &
       if (!(xu & bit)) continue;
       TierPrice Pd;
       if ((rc = price(w2u | bit, xu & ~bit, r, Pd))) return rc;
-      if (R.within_refined(Pd)) { xu &= ~bit; w2u |= bit; kept = Pd; }
+      if (admit_refined(Pd)) { xu &= ~bit; w2u |= bit; kept = Pd; }
     }
     P = kept;
   }
   (void)x_mask;
-  if (ok) { out.w2 = true; out.w2_units = w2u; out.x_units = xu; out.price = P; return 0; }
+  if (ok) { out.w2 = true; out.w2_units = w2u; out.x_units = xu; out.price = figures(P); out.mag_thr = guarded ? thr : 0.f; out.mag_flag = guarded ? flag : 0.f; return 0; }
   // 6. (round 5) the exact-lite arithmetic everywhere, before the exact one
   if (!F.no_lite && !force_mask && !force_x) {
     TierPrice PL;
@@ -251,10 +284,11 @@ inline int search_tier_small(TierPricer &pr, const TierRules &R, const TierForce
 
 // CPU test hook (exported from libmltcnn_hip.so, NOT part of include/mltcnn.h): the search over a caller-supplied pricer.
 //   kind 0: search_tier_128 (n = realisations of the rounding), kind 1: search_tier_small (n = stages)
-//   price_cb(user, w2_units, x_units, rounding, out[3] = {rms, max, tail}) -> 0 or an error code (returned unchanged); the exact-lite tier is
+//   price_cb(user, w2_units, x_units, rounding, out[9] = {rms, max, tail, g_valid, g_rms, g_max, g_tail, g_thr, g_flag}) -> 0 or an error code (returned
+//   unchanged; out arrives zeroed, so a callback that writes the first three figures prices a tier without a magnitude guard); the exact-lite tier is
 //   priced as price_cb(user, ~0u, ~0u, 0, out), where a NEGATIVE return means "no such tier"
-//   force[11] = {rounding, w2_mask, x_mask, w2_units, small_prefix, no_roundings, no_w2, no_xmix, no_w2_units, no_x_units, no_lite}; NULL = nothing forced
-//   result[8] <- {exact, w2, w2_units, x_units, rounding, priced, lite, 0}; figures[3] <- {rms, max, tail} of the choice
+//   force[12] = {rounding, w2_mask, x_mask, w2_units, small_prefix, no_roundings, no_w2, no_xmix, no_w2_units, no_x_units, no_lite, no_mag_guard}; NULL = nothing forced
+//   result[8] <- {exact, w2, w2_units, x_units, rounding, priced, lite, behind the magnitude guard}; figures[4] <- {rms, max, tail, magnitude threshold} of the choice
 extern "C" int mlt_tier_search_run(int kind, int n, float tolerance, float max_frac, const int *force,
                                    int (*price_cb)(void *user, unsigned w2_units, unsigned x_units, int rounding, float *out3), void *user,
                                    int *result, float *figures);

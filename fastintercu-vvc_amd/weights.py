@@ -83,3 +83,15 @@ def from_checkpoint(obj, arch: int) -> bytes:
 
 def synthetic_blob(arch: int, weight_seed: int) -> bytes:
     return pack_blob(arch, synth.make_state_dict(arch, weight_seed))
+
+
+def amplifying_blob(arch: int, weight_seed: int, resi_gain: float = 16.0, org_gain: float = 0.25) -> bytes:
+    """A deterministic stand-in for what TRAINING does to the first layer (round 6; tools/attribute_error.py): the seeded set with the stem's
+    residual-plane filters scaled up and its org-plane filters scaled down.  Like a trained set (tools/train_synth_weights.py) it amplifies the
+    residual plane, so content with residuals of hundreds of ten-bit steps -- the synthetic calibration classes "uniform", "constant org / pred"
+    -- produces features, logits and absolute fp16 errors many times those of ordinary content: the weight family the MAGNITUDE guard exists for
+    (mlt_arith_info.mag_guard_thr), available to tests and probes without a training run."""
+    sd = {k: np.array(v, copy=True) for k, v in synth.make_state_dict(arch, weight_seed).items()}
+    sd["conv1.weight"][:, 1] *= np.float32(resi_gain)
+    sd["conv1.weight"][:, 0] *= np.float32(org_gain)
+    return pack_blob(arch, sd)

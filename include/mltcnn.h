@@ -70,6 +70,7 @@ enum {
 #define MLT_FLAG_EXACT_LITE 0x40u      /* ABI 4 (round 5, measurement): sizes configured exact (MLT_FLAG_EXACT_128; 64/32/16 with MLT_FLAG_NO_CALIBRATION) run the
                                           "exact-lite" arithmetic: Wh*Xh in fp16, the two cross terms Wl*Xh + Wh*Xl as ONE scaled FP8 MFMA per tap and 32 channels
                                           (2 fp16-equivalent MFMAs per product instead of 3; |dlogit| ~ 1/20 of the single pass's) */
+#define MLT_FLAG_NO_MAGNITUDE_GUARD 0x80u /* round 6 (measurement only): never admit a tier behind the magnitude guard (mlt_arith_info.mag_guard_thr): the round-5 search */
 #define MLT_FLAG_NO_DECISION_GUARD 0x20u /* ABI 4: fast arithmetic without the decision guard (measurement only: a split whose reference margin is
                                           below ~2 x tolerance may then differ from the reference's) */
 
@@ -161,6 +162,16 @@ typedef struct mlt_arith_info {
   int32_t rounding;       /* ABI 3: which realisation of the single-pass weights' tap-diffused rounding the calibration kept (0 = the default) */
   int32_t calib_cus;      /* ABI 4: CUs the last calibration priced (synthetic + caller's, without those the flat guard re-evaluates exactly anyway) */
   int32_t calib_caller_cus; /* ABI 4: ... of which supplied by the caller through mlt_calibrate */
+  /* ---- round 6 (appended: written only when struct_size covers them; a 72-byte ABI-4 struct is still accepted) ----
+   * MAGNITUDE guard.  The fp16 tiers' error is relative: it scales with M = max over logits of sum_k |w_ck gap_k|, the size of the feature-driven
+   * part of the logits (the head's poc / qp / bias terms are exact).  A weight set that amplifies content far outside its training range -- a
+   * residual plane of hundreds of ten-bit steps -- produces logits and absolute errors 20-80 x those of ordinary content there; such a set is
+   * admitted to a non-exact tier BEHIND this guard: CUs with M > mag_guard_thr are re-evaluated with the exact arithmetic (third guard beside
+   * the flat-content and the decision guard, same re-run path, counted in guard_reruns).  The threshold is where the tier's worst relative error
+   * measured at load time reaches 0.65 x tolerance; the admission figures (calib_rms / calib_max) are then those of the calibration CUs at or
+   * below it, including 320 further in-distribution CUs (texture + 1/f scenes).  0: the tier was admitted by the plain rule, no such guard. */
+  float mag_guard_thr;
+  float mag_guard_flagged;  /* fraction of the in-distribution calibration CUs (texture, 1/f scenes, the caller's) above the threshold: what the guard costs on ordinary content */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 

@@ -26,6 +26,9 @@ pkg = mltcnn_pkg.load()
 torch.set_num_threads(8)
 
 
+_DITHER = {}
+
+
 def rn16(x):
     return x.to(torch.float16).to(torch.float32)
 
@@ -77,8 +80,37 @@ class Emul:
         """Round an activation tensor for storage (fp16).  Strategies:
         rn (default) | hilo (keep x - rn16(x) as a second fp16 plane => returns hi+lo as fp32) | dither"""
         mode = self.opts.get("act", {}).get(name, self.opts.get("act_default", "rn"))
+        rec = self.opts.get("record")
+        if rec is not None:  # tools/attribute_error.py: the unrounded tensor and what the site stores
+            y = self._act(x, name, mode)
+            rec[name] = (x.clone(), y.clone())
+            return y
+        return self._act(x, name, mode)
+
+    def _act(self, x, name, mode):
         if mode == "rn":
             return rn16(x)
+        if mode == "pdither":
+            # position-keyed sub-ulp dither (VERDICT r5 item 1b): a deterministic offset in [-1/2, 1/2) ulp, a function of (channel, y, x) only --
+            # the same for every CU and every kernel form -- added before the round-to-nearest.  Spatially constant activations then round up at
+            # some pixels and down at others, in proportion to their position inside the fp16 interval: the pooled mean is unbiased.
+            amp = float(self.opts.get("dither_amp", 1.0))
+            n, c, h, w = x.shape
+            key = (self.opts.get("dither_key", 0), c, h, w)
+            if key not in _DITHER:
+                ci = torch.arange(c, dtype=torch.int64).view(c, 1, 1)
+                yi = torch.arange(h, dtype=torch.int64).view(1, h, 1)
+                xi = torch.arange(w, dtype=torch.int64).view(1, 1, w)
+                hsh = (ci * 0x9E3779B1 + yi * 0x85EBCA77 + xi * 0xC2B2AE3D + key[0] * 0x27D4EB2F) & 0xFFFFFFFF
+                hsh = ((hsh ^ (hsh >> 15)) * 0x2C1B3C6D) & 0xFFFFFFFF
+                hsh = ((hsh ^ (hsh >> 12)) * 0x297A2D39) & 0xFFFFFFFF
+                hsh = hsh ^ (hsh >> 15)
+                _DITHER[key] = ((hsh & 0xFFFF).to(torch.float32) / 65536.0 - 0.5).view(1, c, h, w)
+            u = _DITHER[key] * amp
+            # ulp of fp16 at |x| (normals: 2^(e - 10); below 2^-14: 2^-24)
+            e = torch.floor(torch.log2(x.abs().clamp(min=2.0 ** -14)))
+            ulp = torch.pow(2.0, e - 10.0)
+            return rn16(x + u * ulp)
         if mode == "hilo":
             hi = rn16(x)
             return hi + rn16(x - hi)
@@ -178,10 +210,12 @@ class Emul:
             feats.append(outf.mean(dim=(2, 3)))
             cur = self.act(outf, f"l{s}.1.out")
         extra = torch.tensor(np.stack([poc, qp], 1).astype(np.float32))
-        outs = []
+        outs, mags = [], []
         for s in (1, 2, 3):
             w = torch.from_numpy(sd[f"branch{s}.weight"].astype(np.float32)); b = torch.from_numpy(sd[f"branch{s}.bias"].astype(np.float32))
             outs.append(F.linear(torch.cat([feats[s - 1], extra], 1), w, b))
+            mags.append(F.linear(feats[s - 1].abs(), w[:, :-2].abs()))   # sum_k |w_ck gap_k|: the magnitude the fp16 pipeline's relative error acts on
+        self.last_mag = torch.cat(mags, 1).numpy()
         return torch.cat(outs, 1).numpy()
 
 
@@ -196,6 +230,9 @@ STRATEGIES = {
     "stem_hilo": {"w_hilo": ["stem"]},
     "dither": {"act_default": "dither"},
     "dither+stem": {"act_default": "dither", "w_hilo": ["stem"]},
+    "pdither": {"act_default": "pdither"},
+    "pdither_l01": {"act": {k: "pdither" for k in ("l0.0.t", "l0.0.out", "l0.1.t", "l0.1.out", "l1.0.t", "l1.0.sc", "l1.0.out", "l1.1.t", "l1.1.out")}},
+    "pdither_half": {"act_default": "pdither", "dither_amp": 0.5},
 }
 
 

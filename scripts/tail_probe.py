@@ -48,7 +48,7 @@ def main():
         m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob})
         e = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, flags=pkg.capi.FLAG_EXACT_128 if size == 128 else pkg.capi.FLAG_NO_CALIBRATION)
         ar = m.arithmetic(size)
-        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 hi+lo weights in stages 0x{ar['w2_stages']:x}, 2 hi+lo weights everywhere, 4 exact in stages 0x{ar['x_stages']:x} + hi+lo weights in 0x{ar['w2_stages']:x}, 1 exact), exact units 0x{ar['x_units']:x}, hi+lo units 0x{ar['w2_units']:x}; calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}", flush=True)
+        print(f"seed {seed}: tier {ar['exact']} (0 fast, 3 hi+lo weights in stages 0x{ar['w2_stages']:x}, 2 hi+lo weights everywhere, 4 exact in stages 0x{ar['x_stages']:x} + hi+lo weights in 0x{ar['w2_stages']:x}, 1 exact), exact units 0x{ar['x_units']:x}, hi+lo units 0x{ar['w2_units']:x}; calibration worst rms {ar['calib_rms']:.2e} max {ar['calib_max']:.2e}; magnitude guard threshold {ar['mag_guard_thr']:.3g} (0 = none; {100 * ar['mag_guard_flagged']:.1f} % of the in-distribution calibration CUs above it)", flush=True)
         tot_n = tot_bad = 0
         worst = 0.0
         for name, _ in classes:

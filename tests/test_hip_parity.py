@@ -1127,3 +1127,68 @@ def test_layer0_stream_under_the_other_tiers(gpu, seed):
     ref, ref_split = oracle.Oracle(blob).forward(org[:64], pred[:64], poc[:64], qp[:64], threads=8)
     assert np.abs(l[:64] - ref).max() <= LOGIT_TOL
     m.close()
+
+
+def test_magnitude_guard(gpu):
+    """Round 6.  A weight set that amplifies the residual plane -- what training leaves behind; here the deterministic stand-in
+    weights.amplifying_blob -- has logits, and absolute fp16 errors, many times larger on content with huge residuals (the calibration classes
+    "uniform", "constant org / pred") than on ordinary content: the plain admission rule keeps it out of every fp16 tier (round 5: exact-lite at
+    a quarter of the headline).  The error is RELATIVE to the logit magnitude M (heads_kernel: max over logits of sum_k |w_ck gap_k|), so the set
+    is admitted BEHIND the magnitude guard: CUs with M above the threshold are re-evaluated exactly, the others meet the contract.
+    Checked: the tier and its figures, the threshold's meaning, the oracle on mixed content (ordinary CUs on the fp16 tier, huge-residual CUs
+    re-run), the same bits through every entry point, and MLT_FLAG_NO_MAGNITUDE_GUARD = the round-5 outcome."""
+    from oracle import Oracle
+    pkg = gpu
+    size = 128
+    blob = pkg.weights.amplifying_blob(0, 10)
+    m = _ctx(pkg, size, blob)
+    a = m.arithmetic(size)
+    print("behind the magnitude guard:", a)
+    assert a["calibrated"] == 1 and a["exact"] in (0, 2, 3, 4) and a["mag_guard_thr"] > 0.0, a
+    assert 0.0 <= a["mag_guard_flagged"] <= 0.05 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.65e-3 and a["calib_cus"] == 560
+    plain = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_MAGNITUDE_GUARD)
+    ap = plain.arithmetic(size)
+    print("plain rule:", ap)
+    assert ap["mag_guard_thr"] == 0.0 and ap["exact"] in (1, 4, 5), ap          # (what round 5 gave this family: exact stages, exact-lite or exact)
+    # mixed content: texture (ordinary), natural scenes, uniform noise / constant planes (huge residuals)
+    nt, nn, nu = 96, 64, 24
+    ot, pt = pkg.synth.make_patches_bulk(size, nt, 8101)
+    on, pn = pkg.synth.natural_patches(size, nn, 8102)
+    ou, pu = pkg.synth.make_patches(size, nu, 8103, pkg.synth.KIND_UNIFORM)
+    oc, pc = pkg.synth.make_patches(size, nu, 8104, pkg.synth.KIND_ORG_FLAT_PRED_TEX)
+    org = np.concatenate([ot, on, ou, oc]); pred = np.concatenate([pt, pn, pu, pc])
+    n = len(org)
+    poc, qp = pkg.synth.make_scalars(n, 8105)
+    ref, ref_split = Oracle(blob).forward(org, pred, poc, qp, threads=8)
+    r0 = m.arithmetic(size)["guard_reruns"]
+    s, l = m.predict_batch(org, pred, poc, qp)
+    reruns = m.arithmetic(size)["guard_reruns"] - r0
+    err = np.abs(l - ref).max(axis=1)
+    print(f"max |dlogit|: texture {err[:nt].max():.2e} natural {err[nt:nt + nn].max():.2e} uniform {err[nt + nn:nt + nn + nu].max():.2e} constant org {err[-nu:].max():.2e}; "
+          f"{reruns} of {n} CUs re-run exactly; |logit| max {np.abs(ref).max():.1f}")
+    assert err.max() <= LOGIT_TOL
+    check_splits(s, ref, ref_split, head_slices([2, 3, 4])[2], True, LOGIT_TOL, "magnitude guard")
+    assert reruns >= 2 * nu - 4, "the huge-residual CUs are what the guard exists for"
+    assert reruns <= 2 * nu + (nt + nn) // 4, "ordinary content must stay on the fp16 tier"
+    # the re-run CUs carry the exact arithmetic's bits
+    ex = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
+    se, le = ex.predict_batch(org[-nu:], pred[-nu:], poc[-nu:], qp[-nu:])
+    same = (l[-nu:] == le).all(axis=1)
+    assert same.sum() >= nu - 2, same
+    # every entry point: one CU per call, the deferred path, sub-batches
+    for i in (0, nt + 3, nt + nn + 1, n - 1):
+        s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+        assert s1 == s[i] and np.array_equal(l1, l[i]), i
+    tk = [m.submit(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(nt + nn - 4, nt + nn + 8)]
+    m.flush(size)
+    for j, i in enumerate(range(nt + nn - 4, nt + nn + 8)):
+        s1, l1 = m.wait(size, tk[j])
+        assert s1 == s[i] and np.array_equal(l1, l[i]), ("deferred", i)
+    s2, l2 = m.predict_batch(org[nt - 8:nt + nn + 8], pred[nt - 8:nt + nn + 8], poc[nt - 8:nt + nn + 8], qp[nt - 8:nt + nn + 8])
+    assert np.array_equal(l2, l[nt - 8:nt + nn + 8]) and np.array_equal(s2, s[nt - 8:nt + nn + 8])
+    # the seeded bench set is admitted by the plain rule: no magnitude guard, nothing changes for it
+    b10 = _ctx(pkg, size, pkg.weights.synthetic_blob(0, 10))
+    a10 = b10.arithmetic(size)
+    assert a10["exact"] == 0 and a10["mag_guard_thr"] == 0.0 and a10["mag_guard_flagged"] == 0.0
+    for c in (m, plain, ex, b10):
+        c.close()

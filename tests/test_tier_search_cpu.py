@@ -41,15 +41,17 @@ def run(pkg):
             if fail_at is not None and len(calls) == fail_at:
                 return 5
             v = table(w2u, xu, r) if callable(table) else table.get((w2u, xu, r), default)
-            out[0], out[1], out[2] = v
+            for i, x in enumerate(v):   # 3 figures, or 9: + (g_valid, g_rms, g_max, g_tail, g_thr, g_flag) = the same configuration behind the magnitude guard
+                out[i] = x
             return 0
-        res, fig = (C.c_int * 8)(), (C.c_float * 3)()
+        res, fig = (C.c_int * 8)(), (C.c_float * 4)()
         f = None
         if force:
-            f = (C.c_int * 11)(*[force.get(k, d) for k, d in (("rounding", -1), ("w2_mask", -1), ("x_mask", -1), ("w2_units", -1), ("small_prefix", -1),
-                                                            ("no_roundings", 0), ("no_w2", 0), ("no_xmix", 0), ("no_w2_units", 0), ("no_x_units", 0), ("no_lite", 0))])
+            f = (C.c_int * 12)(*[force.get(k, d) for k, d in (("rounding", -1), ("w2_mask", -1), ("x_mask", -1), ("w2_units", -1), ("small_prefix", -1),
+                                                            ("no_roundings", 0), ("no_w2", 0), ("no_xmix", 0), ("no_w2_units", 0), ("no_x_units", 0), ("no_lite", 0), ("no_mag_guard", 0))])
         rc = lib.mlt_tier_search_run(kind, n, TOL, max_frac, f, CB(cb), None, res, fig)
-        return dict(rc=rc, exact=res[0], w2=res[1], w2_units=res[2], x_units=res[3], rounding=res[4], priced=res[5], lite=res[6], rms=fig[0], max=fig[1], tail=fig[2]), calls
+        return dict(rc=rc, exact=res[0], w2=res[1], w2_units=res[2], x_units=res[3], rounding=res[4], priced=res[5], lite=res[6], guarded=res[7], rms=fig[0], max=fig[1], tail=fig[2],
+                    mag_thr=fig[3]), calls
     return go
 
 
@@ -209,3 +211,57 @@ def test_a_failing_pricer_stops_the_search_with_its_code(run):
     assert r["rc"] == 5 and calls == [(0, 0, 0), "lite"]
     r, calls = run(1, 5, {}, fail_at=1)
     assert r["rc"] == 5 and len(calls) == 1
+
+
+def guarded(plain, behind, thr=4.0, flag=0.02):
+    return tuple(plain) + (1.0,) + tuple(behind) + (thr, flag)
+
+
+def test_magnitude_guard_admits_what_the_plain_rule_rejects(run):
+    """Round 6: a configuration the plain rule rejects may be admitted BEHIND the magnitude guard when the pricer supplies the figures over the
+    CUs below the guard's threshold -- same constants, the plain rule first, at most 5 % of the in-distribution CUs above the threshold."""
+    # the single pass, default realisation: priced once, admitted behind the guard; the choice reports the guarded figures and the threshold
+    r, calls = run(0, 6, {(0, 0, 0): guarded(BAD, GOOD, thr=4.0)})
+    assert (r["exact"], r["w2"], r["lite"], r["guarded"]) == (0, 0, 0, 1) and calls == [(0, 0, 0)]
+    assert abs(r["mag_thr"] - 4.0) < 1e-6 and abs(r["max"] - GOOD[1]) < 1e-9 and abs(r["rms"] - GOOD[0]) < 1e-9
+    # the plain rule has priority: a configuration within it is admitted without the guard even when guarded figures come along
+    r, _ = run(0, 6, {(0, 0, 0): guarded(GOOD, GOOD)})
+    assert (r["guarded"], r["mag_thr"]) == (0, 0.0)
+    # too many in-distribution CUs above the threshold (> 5 %): not admitted, the search goes on as before
+    r, calls = run(0, 6, {(0, 0, 0): guarded(BAD, GOOD, flag=0.2)}, default=GOOD, force={"no_roundings": 1})
+    assert r["guarded"] == 0 and r["w2"] == 1 and calls[1] == (units(W2_ORDER[0]), 0, 0)
+    # guarded figures outside the rule, a threshold of zero, or figures flagged invalid: no admission
+    for v in (guarded(BAD, BAD), guarded(BAD, GOOD, thr=0.0), BAD + (0.0,) + GOOD + (4.0, 0.0)):
+        r, _ = run(0, 1, {(0, 0, 0): v}, lite=BAD)
+        assert (r["exact"], r["guarded"]) == (1, 0)
+    # switched off (MLT_FLAG_NO_MAGNITUDE_GUARD / the small models): the round-5 search
+    r, _ = run(0, 1, {(0, 0, 0): guarded(BAD, GOOD)}, lite=BAD, force={"no_mag_guard": 1})
+    assert (r["exact"], r["guarded"]) == (1, 0)
+    # another rounding realisation behind the guard is taken before any hi+lo-weights tier
+    r, calls = run(0, 6, {(0, 0, 0): BAD, (0, 0, 1): guarded(BAD, GOOD, thr=5.5)})
+    assert (r["rounding"], r["guarded"], r["w2"]) == (1, 1, 0) and calls == [(0, 0, 0), (0, 0, 1)] and abs(r["mag_thr"] - 5.5) < 1e-6
+
+
+def test_refinements_of_a_guarded_tier_are_judged_behind_the_guard(run):
+    """A hi+lo-weights stage subset admitted behind the guard: its unit drops are held to the REFINED rule on the guarded figures, and the threshold
+    reported is the one of the configuration that is kept (every configuration has its own: the threshold follows its worst relative error)."""
+    base = units(0x2)                                   # layer1 in hi+lo weights: units 2 and 3
+    def table(w, x, r):
+        if (w, x) == (0, 0):
+            return BAD
+        if w == base:
+            return guarded(BAD, GOOD, thr=6.0)
+        if w == base & ~(1 << 3):                       # first drop (unit 3, the 64-channel chain): refined rule holds behind the guard
+            return guarded(BAD, GOOD, thr=5.0)
+        if w == 0 and x == 0:
+            return BAD
+        return guarded(BAD, EDGE, thr=4.5)              # further drops: within, but not within the refined rule
+    r, calls = run(0, 1, table)
+    assert (r["w2"], r["guarded"]) == (1, 1) and r["w2_units"] == base & ~(1 << 3) and abs(r["mag_thr"] - 5.0) < 1e-6
+    # a refinement that passes the PLAIN refined rule but brings no guarded figures is not taken while the tier sits behind the guard
+    def table2(w, x, r):
+        if (w, x) == (0, 0):
+            return BAD
+        return guarded(BAD, GOOD, thr=6.0) if w == base else GOOD
+    r, _ = run(0, 1, table2)
+    assert (r["w2"], r["guarded"], r["w2_units"]) == (1, 1, base) and abs(r["mag_thr"] - 6.0) < 1e-6
