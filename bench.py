@@ -169,6 +169,17 @@ def main():
                 "weight_blob_bytes": len(blob), "weight_broadcast_ms": round(bcast_ms, 3)}
     m = pkg.MltCnn(device=dev_index, sizes=(size,), blobs={size: blob}, max_batch=B, flags=args.flags)
     arith = m.arithmetic(size)  # fast or exact (load-time calibration), guards
+    if dist is not None:
+        # every rank calibrated its own copy of the weights: they must have landed on the SAME arithmetic (rank 0's is broadcast and compared;
+        # a mismatch raises on every rank) -- an N-rank line never mixes tiers
+        try:
+            pkg.shard.agree_on_arithmetic(arith, dist)
+        except RuntimeError as e:
+            print(f"bench.py: {e}", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(4)
+        if rccl is not None:
+            rccl["arithmetic_agreed"] = True
 
     # ---- synthetic inputs: rank r owns CUs [r*B, (r+1)*B) of the global batch ----
     if args.flat_frac > 0 or args.content != "texture":

@@ -65,6 +65,10 @@ struct SizeState {
                                // model (two activation planes, FP8 cross terms; mlt_model.h: xl), the flat guard is off (its error is 1/20 of the single
                                // pass's), the decision guard -- if configured -- still re-evaluates near-ties with `model_exact`
   bool cfg_flat_guard = false; // flat guard as configured (flags); flat_guard is what the loaded tier uses
+  int flat_div = 8;            // the flat guard re-evaluates a CU when >= 1 / flat_div of its quads are EXACTLY flat.  8 for the fp16 tiers; 16 for the exact-lite
+                               // tier (round 6: its FP8 cross terms quantise a constant area's activations coherently -- 3-bit mantissas -- and a weight set with
+                               // large logits turns a 10-12 % constant band into |dlogit| 1.0-1.5e-3: 4 of 331,776 probed logits of the second trained family,
+                               // profiles/r06b_tail_probe_trained.txt; round 5 had switched the guard OFF for this tier on the strength of the seeded sets)
   float guard_margin = 3e-3f;  // decision guard's threshold for THIS size's tier: the context's (3 x tolerance, or as configured) -- except the exact-lite tier, whose
                                // largest calibration error is ~ 1/6 of the tolerance: 3 x 1.7 x calib_max there (1.7: the tail probes' largest error over the
                                // calibration set's), at least 1e-4, at most the context's
@@ -685,8 +689,10 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       HIP_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
       if ((rc = L.prof_end(e1))) return rc;
     }
-    // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups)
-    static const int l0_min = [] { const char *e = tuning_env("MLT_L0_STREAM_MIN"); return tuning_env("MLT_NO_L0_STREAM") ? 0 : e ? std::atoi(e) : 256; }();
+    // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups).
+    // Round 6: from 128 CUs on -- the measured crossover (one CU per workgroup on half the chip already beats the tiled launches: docs/KERNEL_NOTES.md,
+    // "Where the streaming launches start to pay": 128 CUs +3 %, 192 CUs +12 %); round 5 had kept 256
+    static const int l0_min = [] { const char *e = tuning_env("MLT_L0_STREAM_MIN"); return tuning_env("MLT_NO_L0_STREAM") ? 0 : e ? std::atoi(e) : 128; }();
     if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && l0_min > 0 && n >= l0_min) {
       // ... and with it the stride-2 conv + shortcut that open layer1, when the 64-channel chain follows (it wants sc chunk-major) and layer1's first
       // unit runs the single pass too: layer0's output then never reaches HBM
@@ -723,8 +729,8 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       }
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
-        // round 5: batches of >= 256 CUs run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain)
-        static const int l1_min = [] { const char *e = tuning_env("MLT_L1_STREAM_MIN"); return tuning_env("MLT_NO_L1_STREAM") ? 0 : e ? std::atoi(e) : 256; }();
+        // round 5: large batches run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain); round 6: from 128 CUs on
+        static const int l1_min = [] { const char *e = tuning_env("MLT_L1_STREAM_MIN"); return tuning_env("MLT_NO_L1_STREAM") ? 0 : e ? std::atoi(e) : 128; }();
         const mlt::PackedConv &q2 = B0c.conv2;
         if (s == 1 && !chain_s2 && m.planes[s] == 64 && hout == 32 && io.ysc_c16 && !mt.w2 && !mt.exact && l1_min > 0 && n >= l1_min &&
             q2.taps == 9 && q2.kc == 64 && q2.ct == 64 && outs[s] && !last) {
@@ -861,7 +867,7 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
     // one CU (mlt_predict's captured graph): the selection is a tail of the heads kernel -- no guard_select launch, no memset of the
     // statistic (the tail clears it for the next call; it is only consumed when the first kernel is the one that produces it: aligned planes,
     // S >= 64 -- else flat_stat_kernel overwrites it), no separate copy of the count (the caller's result copy carries it)
-    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / 8, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr};
+    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr};
     return run_main(ctx, st, 1, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg, st.flat_guard ? g.d_flat : nullptr, &tail, true);
   }
   float *mg = st.mag_thr > 0.f ? g.d_mag : nullptr;
@@ -875,7 +881,7 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   int off = 0;
   for (int h = 0; h < st.head_index; ++h) off += st.model.heads[h].classes;
   sa.head_off = off; sa.head_classes = st.model.heads[st.head_index].classes;
-  sa.flat_thr = (S * S / 4) / 8;  // >= 1/8 of the quads exactly flat (constant / exactly linear in both planes)
+  sa.flat_thr = (S * S / 4) / st.flat_div;  // >= 1/8 (exact-lite tier: 1/16) of the quads exactly flat (constant / exactly linear in both planes)
   sa.near_thr = (S * S / 4) / 2;  // or >= 1/2 of them near-flat (mlt_kernels.h: MLT_FLAT_RANGE)
   sa.margin = st.margin_guard ? st.guard_margin : 0.f;
   if ((rc = L.prof_begin("guard_select", 0.0, 0.0, e0, e1))) return rc;
@@ -1172,10 +1178,10 @@ struct CalibSession {
   }
   // which CUs of t[first ..) the flat-content guard re-evaluates exactly at run time (flat_stat_kernel's statistic, guard_select_kernel's
   // thresholds): those never see the arithmetic being priced
-  int drop_flat(Set &t, int first) {
+  int drop_flat(Set &t, int first, int div = 8, std::vector<char> *mask = nullptr) {
     const int S = st.size, cnt = t.n - first;
     const size_t cs = (size_t)S * S;
-    if (!st.flat_guard || cnt <= 0) return MLT_OK;
+    if (!st.cfg_flat_guard || cnt <= 0) return MLT_OK;
     FlatStatArgs fa{};
     fa.org = t.d_org + cs * first; fa.pred = t.d_pred + cs * first; fa.org_row_stride = S; fa.org_cu_stride = (long)cs; fa.pred_row_stride = S;
     fa.pred_cu_stride = (long)cs; fa.flat = t.d_split; fa.n = cnt; fa.s_l = ilog2(S);
@@ -1183,9 +1189,10 @@ struct CalibSession {
     std::vector<int32_t> fl((size_t)cnt);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(fl.data(), t.d_split, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-    const int flat_thr = (S * S / 4) / 8, near_thr = (S * S / 4) / 2;
+    const int flat_thr = (S * S / 4) / div, near_thr = (S * S / 4) / 2;
+    std::vector<char> &u = mask ? *mask : t.use;
     for (int i = 0; i < cnt; ++i)
-      if ((fl[(size_t)i] >> MLT_FLAT_EXACT_SHIFT) >= flat_thr || (fl[(size_t)i] & 0xFFFF) >= near_thr) t.use[(size_t)(first + i)] = 0;
+      if ((fl[(size_t)i] >> MLT_FLAT_EXACT_SHIFT) >= flat_thr || (fl[(size_t)i] & 0xFFFF) >= near_thr) u[(size_t)(first + i)] = 0;
     return MLT_OK;
   }
   int run(Set &t, std::vector<float> &out, bool exact, unsigned mask, unsigned xmask = 0, mlt::Model *whole = nullptr, bool with_mag = false) {
@@ -1299,7 +1306,13 @@ struct CalibSession {
     if (rc) return rc;
     TierPrice_ P;
     const Set *sets[1] = {&main};
+    std::vector<char> keep_use;
+    if (whole && st.cfg_flat_guard) {  // the exact-lite tier runs behind the flat guard at 1 / 16 (SizeState.flat_div): the CUs THAT guard re-evaluates do not count
+      keep_use = main.use;
+      if ((rc = drop_flat(main, 0, 16))) return rc;
+    }
     pool(sets, 1, 0.f, P);
+    if (!keep_use.empty()) main.use = keep_use;
     tail_ratio = P.tail;
     if (std::getenv("MLT_CALIB_VERBOSE")) {  // diagnostics: which content class / head decides the admission
       std::fprintf(stderr, "mltcnn calibration (size %d, %d CUs of which %d the caller's, hi+lo weights in units 0x%x, exact in units 0x%x): rms per class", st.size, n_used, n_caller_used, mask, xmask);
@@ -1468,7 +1481,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
   st.loaded = false;
   st.exact = st.want_exact && !small_mix;
-  st.lite = false; st.flat_guard = st.cfg_flat_guard; st.guard_margin = ctx->guard_margin;
+  st.lite = false; st.flat_guard = st.cfg_flat_guard; st.flat_div = 8; st.guard_margin = ctx->guard_margin;
   st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
   st.mag_thr = 0.f; st.calib_rel = 0.f; st.mag_flag = 0.f;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
@@ -1524,9 +1537,10 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
         st.model = std::move(st.model_xl);
         st.model_xl = mlt::Model();
         st.lite = true;
-        st.flat_guard = false;
+        st.flat_guard = st.cfg_flat_guard;   // (round 5 switched it off here; round 6: on, at 1 / 16 of the quads exactly flat)
+        st.flat_div = 16;
         if (!ctx->guard_margin_configured) st.guard_margin = std::min(ctx->guard_margin, std::max(1e-4f, 3.f * 1.7f * st.calib_max));
-        if (!st.margin_guard) { free_model(st.model_exact); st.model_exact = mlt::Model(); }
+        if (!st.margin_guard && !st.flat_guard) { free_model(st.model_exact); st.model_exact = mlt::Model(); }
       } else if (ch.exact) {  // run it exact
         free_model(st.model_w2); st.model_w2 = mlt::Model();
         free_model(st.model_xl); st.model_xl = mlt::Model();

@@ -3,6 +3,8 @@
 CU inferences are independent, so a batch is cut into contiguous rank-local ranges
 (GPU g gets CUs [g*B/G, (g+1)*B/G)) and every rank runs its own `MltCnn` context.  The only exchange steps are
   * init: rank 0 broadcasts the MLTW weight blob (RCCL over xGMI on GPUs, `backend="nccl"`; gloo in the CPU tests),
+  * init: every rank calibrates its own copy of the weights -- the ranks then AGREE on the outcome (rank 0's mlt_arith_info is broadcast and
+    compared, `agree_on_arithmetic`): an N-rank line cannot mix arithmetic tiers silently,
   * optional: all_gather of the int32 split modes / fp32 logits when one rank needs the whole batch.
 """
 from __future__ import annotations
@@ -51,3 +53,26 @@ def gather_results(split: np.ndarray, logits: np.ndarray, total: int, dist, devi
         out_s[lo:hi] = s_all[r][:hi - lo].cpu().numpy()
         out_l[lo:hi] = l_all[r][:hi - lo].cpu().numpy()
     return out_s, out_l
+
+
+# what identifies the arithmetic a rank's load-time calibration chose (mlt_arith_info): two ranks that differ in any of these would produce
+# different bits for the same CU -- and different throughput -- inside one job
+ARITH_KEYS = ("exact", "w2_stages", "w2_units", "x_stages", "x_units", "rounding", "flat_guard", "decision_guard", "guard_margin", "mag_guard_thr")
+
+
+def agree_on_arithmetic(arith: dict, dist, src: int = 0) -> dict:
+    """Rank `src` broadcasts the arithmetic its calibration chose (the ARITH_KEYS of MltCnn.arithmetic()); every rank compares its own with it
+    and raises on a mismatch (after an all_gather of the verdicts, so that ALL ranks fail together instead of some hanging in the next
+    collective).  Returns the agreed dict.  The calibration is deterministic (same blob, same kernels, same synthetic CUs), so a mismatch
+    means different library builds, different GPUs or a faulty device -- in every case a line that must not be reported as one job."""
+    mine = {k: (round(float(arith[k]), 9) if isinstance(arith[k], float) else int(arith[k])) for k in ARITH_KEYS}
+    box = [mine if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src)
+    ref = box[0]
+    ok = mine == ref
+    verdicts = [None] * dist.get_world_size()
+    dist.all_gather_object(verdicts, (dist.get_rank(), ok, mine))
+    bad = [(r, m) for r, good, m in verdicts if not good]
+    if bad:
+        raise RuntimeError(f"ranks calibrated to different arithmetic tiers: rank {src} has {ref}, but " + "; ".join(f"rank {r} has {m}" for r, m in bad))
+    return ref

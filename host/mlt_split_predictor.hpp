@@ -16,7 +16,8 @@
 // small for the fast arithmetic's calibrated error to leave the argmax alone is re-evaluated with the exact arithmetic before the call returns.
 //
 // MLTCNN_STATS=1 (any build): the destructor prints ONE line to stderr -- calls and wall-clock seconds inside predictSplitMode / submit /
-// flush / wait, calls per CU size -- the "share of an encode spent inside the predictor" figure tools/eval_harness.py reads (N4).
+// flush / wait, calls per CU size, seconds inside mlt_init (weights + calibration) -- the "share of an encode spent inside the predictor" figure
+// tools/eval_harness.py reads (N4).
 //
 // Test hooks, compiled in only with -DMLTCNN_TEST_HOOKS (tools/build_vtm.sh does; a production build carries none of them):
 //   MLTCNN_FAULT_INJECT=1      the predictor reports ok() without touching a device and every predictSplitMode() fails (-1):
@@ -73,7 +74,9 @@ class SplitPredictor {
     if (const char *f = std::getenv("MLTCNN_FORCE_SPLIT")) m_forceSplit = std::atoi(f);
     if (m_faultInject) return;
 #endif
-    const int rc = mlt_init(&cfg, &m_ctx);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mlt_init(&cfg, &m_ctx);   // loads, folds, packs and CALIBRATES the weights of every enabled size (once per encoder process)
+    m_initSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != MLT_OK) {
       std::fprintf(stderr, "error loading the model\n");  // the reference's message (EncCu.cpp:904)
       std::fprintf(stderr, "  mltcnn: %s\n", mlt_last_error(nullptr));
@@ -83,8 +86,8 @@ class SplitPredictor {
   ~SplitPredictor() {
     if (m_stats)
       std::fprintf(stderr, "mltcnn-stats predict_calls=%llu predict_s=%.6f submit_calls=%llu submit_s=%.6f wait_calls=%llu wait_s=%.6f flush_calls=%llu flush_s=%.6f "
-                           "calls_128=%llu calls_64=%llu calls_32=%llu calls_16=%llu failed=%llu\n",
-                   m_n[0], m_t[0], m_n[1], m_t[1], m_n[2], m_t[2], m_n[3], m_t[3], m_bySize[0], m_bySize[1], m_bySize[2], m_bySize[3], m_failed);
+                           "calls_128=%llu calls_64=%llu calls_32=%llu calls_16=%llu failed=%llu init_s=%.6f\n",
+                   m_n[0], m_t[0], m_n[1], m_t[1], m_n[2], m_t[2], m_n[3], m_t[3], m_bySize[0], m_bySize[1], m_bySize[2], m_bySize[3], m_failed, m_initSeconds);
     mlt_shutdown(m_ctx);
   }
   SplitPredictor(const SplitPredictor &) = delete;
@@ -176,6 +179,7 @@ class SplitPredictor {
   bool m_stats = false;
   unsigned long long m_n[4] = {0, 0, 0, 0}, m_bySize[4] = {0, 0, 0, 0}, m_failed = 0;
   double m_t[4] = {0, 0, 0, 0};
+  double m_initSeconds = 0.0;   // wall-clock of mlt_init (weights + load-time calibration): what an encoder process pays once
 
   mlt_ctx *m_ctx = nullptr;
   uint32_t m_mask = MLT_SIZE_128;

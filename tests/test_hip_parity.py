@@ -1083,7 +1083,7 @@ def test_exact_lite_arithmetic_against_the_oracle(gpu):
 
 def test_layer0_stream_is_bit_identical(gpu):
     """(Also covers layer1_stream_kernel, the 64-channel stage's streaming launch, which switches on at the same batch size.)
-    Round 5: batches of >= 256 CUs of 128 x 128 run ALL of layer0 in one streaming launch (layer0_stream_kernel: four row stages handing rows to
+    Round 5: large batches (>= 128 CUs since round 6) of 128 x 128 run ALL of layer0 in one streaming launch (layer0_stream_kernel: four row stages handing rows to
     each other through LDS rings, b0 never in HBM); smaller batches keep the two tiled launches (stem_block_kernel -> block32_kernel).  Same
     arithmetic in the same order: the logits must agree bit for bit -- 301 CUs (workgroups with one CU and with two; pipeline fill and drain across
     the CU boundary) against the same CUs in sub-batches of 100, flat CUs included (the guard statistic is gathered by the streaming kernel too)."""
@@ -1101,6 +1101,11 @@ def test_layer0_stream_is_bit_identical(gpu):
         b = min(n, a + 100)
         s1, l1 = m.predict_batch(org[a:b], pred[a:b], poc[a:b], qp[a:b])
         assert np.array_equal(l1, l[a:b]) and np.array_equal(s1, s[a:b]), f"streaming layer0 differs from the tiled form in CUs {a}..{b}"
+    # round 6: the streaming launches start at 128 CUs (the measured crossover; 256 in round 5): batches on either side of the threshold and
+    # inside the 128 .. 255 range, where half of the chip's workgroup slots stay empty
+    for k in (127, 128, 129, 200, 255, 256):
+        s1, l1 = m.predict_batch(org[:k], pred[:k], poc[:k], qp[:k])
+        assert np.array_equal(l1, l[:k]) and np.array_equal(s1, s[:k]), f"batch of {k} CUs differs"
     assert m.arithmetic(128)["guard_reruns"] >= 1
     m.close()
 

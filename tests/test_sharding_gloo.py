@@ -73,3 +73,48 @@ def test_shard_bounds_partition(pkg, total, world):
     assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
     sizes = [hi - lo for lo, hi in b]
     assert max(sizes) - min(sizes) <= 1
+
+
+def _agree_worker(rank, world, port, differ, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    import mltcnn_pkg
+    pkg = mltcnn_pkg.load()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arith = {"exact": 0, "w2_stages": 0, "w2_units": 0, "x_stages": 0, "x_units": 0, "rounding": 0, "flat_guard": 1, "decision_guard": 1,
+             "guard_margin": 3e-3, "mag_guard_thr": 0.0, "calib_rms": 1.6e-4 + 1e-6 * rank, "guard_reruns": rank}   # (figures outside ARITH_KEYS may differ)
+    if differ and rank == 1:
+        arith["exact"], arith["w2_units"] = 3, 0xC   # this rank's calibration chose hi+lo weights in layer1
+    try:
+        pkg.shard.agree_on_arithmetic(arith, dist)
+        q.put((rank, "agreed"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("differ", [False, True])
+def test_ranks_agree_on_the_calibrated_arithmetic(pkg, differ):
+    """rank 0's mlt_arith_info is broadcast and compared -- an 8-rank bench line cannot mix arithmetic tiers silently; a
+    mismatch fails on EVERY rank (none is left hanging in the next collective)."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, differ, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if differ:
+        assert all("different arithmetic tiers" in v and "rank 1 has" in v for v in got.values()), got
+    else:
+        assert got == {0: "agreed", 1: "agreed"}

@@ -62,7 +62,8 @@ def parse_predictor_stats(text: str) -> dict:
     calls = {k: int(kv.get(k + "_calls", 0)) for k in ("predict", "submit", "wait", "flush")}
     secs = {k: float(kv.get(k + "_s", 0.0)) for k in ("predict", "submit", "wait", "flush")}
     return {"cnn_calls": calls["predict"] + calls["submit"], "cnn_seconds": sum(secs.values()), "cnn_calls_by_entry": calls, "cnn_seconds_by_entry": secs,
-            "cnn_calls_by_size": {s: int(kv.get(f"calls_{s}", 0)) for s in (128, 64, 32, 16)}, "cnn_failed": int(kv.get("failed", 0))}
+            "cnn_calls_by_size": {s: int(kv.get(f"calls_{s}", 0)) for s in (128, 64, 32, 16)}, "cnn_failed": int(kv.get("failed", 0)),
+            "cnn_init_seconds": float(kv["init_s"]) if "init_s" in kv else None}   # round 6: mlt_init (weights + load-time calibration), once per encoder process
 
 
 def batch_histogram(batch_log_text: str) -> dict:

@@ -17,6 +17,13 @@ one process per (leg, QP), several at a time.
                re-checked against the CPU oracle.  BD-rate is computed by tools/eval_harness.py from the logs the encoder wrote -- with SEEDED
                (untrained) weights it measures the harness, not the method.
 
+  --mode alone (round 6) GPU box: what the call costs the ENCODER when it has the GPU to itself.  The legs that use the GPU (serial:
+               one mlt_predict per CU; MLTCNN_BATCH=0 / =1 under WPP; with >= 2 GPUs also MLTCNN_BATCH=1 over MLTCNN_DEVICES=0,1) run ONE AFTER THE
+               OTHER -- round 5's table ran 24 encoders against one device and read 1-15 ms per call -- while the anchors (no CNN, no GPU) encode
+               beside them on other cores.  Per leg: us per predictSplitMode call, share of the encode's elapsed time, seconds inside mlt_init
+               (weights + load-time calibration: MLTCNN_STATS init_s), batch-size histogram; batched == serial bitstream.  --width 1920 --height 1080
+               --frames 9 is the shape of the reference's script_128/BasketballDrive_enc_50.sh:4-19 (135 CTUs of 128 x 128 per picture).
+
 Writes <out>/summary.json, <out>/table.md and the encoder logs (<out>/<leg>/synth_q<QP>.txt, the reference scripts' naming)."""
 import argparse
 import concurrent.futures as cf
@@ -93,7 +100,7 @@ def check_dump_against_oracle(dump, blobs, tol=1e-3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=("cpu", "gpu"), required=True)
+    ap.add_argument("--mode", choices=("cpu", "gpu", "alone"), required=True)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ra_eval"))
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--height", type=int, default=480)
@@ -109,7 +116,7 @@ def main():
     enc, dec = os.path.join(VTM, "EncoderApp"), os.path.join(VTM, "DecoderApp")
     assert os.path.exists(enc) and os.path.exists(dec), "patched EncoderApp not built (tools/build_vtm.sh, build container)"
     cfg = a.cfg or (REF_CFG if a.mode == "cpu" and os.path.exists(REF_CFG) else OWN_CFG)
-    qps = [int(q) for q in (a.qps or ("32" if a.mode == "cpu" else "22,27,32,37")).split(",")]
+    qps = [int(q) for q in (a.qps or ("22,27,32,37" if a.mode == "gpu" else "32")).split(",")]
     jobs = a.jobs or max(1, min(24, (os.cpu_count() or 8) // (1 if a.mode == "cpu" else 4)))
     os.makedirs(a.out, exist_ok=True)
     import make_synth_yuv
@@ -117,7 +124,7 @@ def main():
     make_synth_yuv.write_yuv(yuv, make_synth_yuv.make_frames(a.width, a.height, a.frames, a.seed))
 
     blobs, wdir = {}, os.path.join(a.out, "torch_model")
-    if a.mode == "gpu":
+    if a.mode in ("gpu", "alone"):
         import mltcnn_pkg
         pkg = mltcnn_pkg.load()
         os.makedirs(wdir, exist_ok=True)
@@ -129,7 +136,16 @@ def main():
     wpp = ["--WaveFrontSynchro=1"]
     for q in qps:
         legs.append(("anchor", q, {"MLTCNN_SIZE_MASK": "0x100"}, []))
-        if a.mode == "cpu":
+        if a.mode == "alone":
+            import torch
+            w = {"MLTCNN_WEIGHTS_DIR": wdir, "MLTCNN_STATS": "1"}
+            legs.append(("wpp_anchor", q, {"MLTCNN_SIZE_MASK": "0x100", "MLTCNN_BATCH": "0"}, wpp))
+            legs.append(("serial", q, dict(w), []))
+            legs.append(("wpp_serial", q, dict(w, MLTCNN_BATCH="0"), wpp))
+            legs.append(("wpp_batch", q, dict(w, MLTCNN_BATCH="1", MLTCNN_BATCH_LOG=os.path.join(a.out, f"batch_q{q}.log")), wpp))
+            if torch.cuda.device_count() >= 2:   # one encoder process over two GPUs (mlt_config.devices: submitted CUs are dealt round-robin)
+                legs.append(("wpp_batch_2gpu", q, dict(w, MLTCNN_BATCH="1", MLTCNN_DEVICES="0,1"), wpp))
+        elif a.mode == "cpu":
             legs.append(("inject", q, {"MLTCNN_FAULT_INJECT": "1"}, []))
             legs.append(("wpp_serial", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_BATCH": "0"}, wpp))
             legs.append(("wpp_batch", q, {"MLTCNN_FAULT_INJECT": "1", "MLTCNN_BATCH": "1", "MLTCNN_BATCH_LOG": os.path.join(a.out, f"batch_q{q}.log")}, wpp))
@@ -163,8 +179,16 @@ def main():
         return name, q, r.returncode, time.time() - t0
 
     t_all = time.time()
-    with cf.ThreadPoolExecutor(jobs) as ex:
-        done = list(ex.map(run, legs))
+    if a.mode == "alone":
+        # the legs that touch the GPU one at a time (this thread); the anchors -- no CNN, no device -- beside them on the pool
+        uses_gpu = lambda leg: "MLTCNN_WEIGHTS_DIR" in leg[2]
+        with cf.ThreadPoolExecutor(4) as ex:
+            fut = [ex.submit(run, l) for l in legs if not uses_gpu(l)]
+            done = [run(l) for l in legs if uses_gpu(l)] + [f.result() for f in fut]
+        jobs = 1
+    else:
+        with cf.ThreadPoolExecutor(jobs) as ex:
+            done = list(ex.map(run, legs))
     bad = [d for d in done if d[2] != 0]
     assert not bad, bad
 
@@ -186,6 +210,9 @@ def main():
             c["n1_inject_equals_anchor"] = logs[("inject", q)]["sha256"] == logs[("anchor", q)]["sha256"]
             c["inject_hello_count"] = logs[("inject", q)]["hello"]
         c["n3_batch_equals_serial"] = logs[("wpp_batch", q)]["sha256"] == logs[("wpp_serial", q)]["sha256"]
+        if ("wpp_batch_2gpu", q) in logs:
+            c["two_gpus_equal_one"] = logs[("wpp_batch_2gpu", q)]["sha256"] == logs[("wpp_batch", q)]["sha256"]
+            ok &= c["two_gpus_equal_one"]
         for fs in [v for v in a.force_splits.split(",") if v and a.mode == "cpu"]:
             c[f"n3_batch_equals_serial_forced_split_{fs}"] = logs[(f"wpp_batch_fs{fs}", q)]["sha256"] == logs[(f"wpp_serial_fs{fs}", q)]["sha256"]
             c[f"forced_split_{fs}_differs_from_full_rdo"] = logs[(f"wpp_serial_fs{fs}", q)]["sha256"] != logs[("wpp_serial", q)]["sha256"]
@@ -218,7 +245,8 @@ def main():
                "cnn_calls": s.get("cnn_calls"), "cnn_seconds": s.get("cnn_seconds"),
                "cnn_share_of_elapsed_pct": round(100.0 * s["cnn_seconds"] / s["time_elapsed_s"], 3) if s.get("cnn_seconds") is not None else None,
                "us_per_call": round(1e6 * s["cnn_seconds"] / s["cnn_calls"], 1) if s.get("cnn_calls") else None,
-               "cnn_calls_by_size": s.get("cnn_calls_by_size"), "sha256": s["sha256"][:16]}
+               "cnn_calls_by_size": s.get("cnn_calls_by_size"), "cnn_init_seconds": s.get("cnn_init_seconds"),
+               "cnn_seconds_by_entry": s.get("cnn_seconds_by_entry"), "sha256": s["sha256"][:16]}
         summ["rows"].append(row)
     if a.mode == "gpu" and len(qps) >= 4:
         bd = {}
@@ -235,11 +263,11 @@ def main():
     summ["ok"] = bool(ok)
     json.dump(summ, open(os.path.join(a.out, "summary.json"), "w"), indent=1, default=str)
     with open(os.path.join(a.out, "table.md"), "w") as f:
-        f.write(f"RA-toolset encodes ({summ['cfg']}; {summ['clip']}; mode {a.mode}; {jobs} encoder processes at a time on {os.cpu_count()} CPUs)\n\n")
-        f.write("| leg | QP | kbps | Y-PSNR | enc user s | enc elapsed s | saving user % | saving elapsed % | CNN calls | s inside predictor | share of elapsed % | us / call |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write(f"RA-toolset encodes ({summ['cfg']}; {summ['clip']}; mode {a.mode}; {jobs} GPU-using encoder process{'es' if jobs > 1 else ''} at a time on {os.cpu_count()} CPUs)\n\n")
+        f.write("| leg | QP | kbps | Y-PSNR | enc user s | enc elapsed s | saving user % | saving elapsed % | CNN calls | s inside predictor | share of elapsed % | us / call | s in mlt_init |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r in summ["rows"]:
             f.write(f"| {r['leg']} | {r['qp']} | {r['kbps']:.2f} | {r['psnr_y']:.3f} | {r['enc_user_s']:.1f} | {r['enc_elapsed_s']:.1f} | {r['time_saving_user_pct']} | {r['time_saving_elapsed_pct']} | "
-                    f"{r['cnn_calls']} | {r['cnn_seconds']} | {r['cnn_share_of_elapsed_pct']} | {r['us_per_call']} |\n")
+                    f"{r['cnn_calls']} | {r['cnn_seconds']} | {r['cnn_share_of_elapsed_pct']} | {r['us_per_call']} | {r['cnn_init_seconds']} |\n")
         f.write("\nchecks: " + json.dumps(summ["checks"], default=str) + "\n")
         if "bd" in summ:
             f.write("\nBD-rate / time saving over the QPs (tools/eval_harness.py; SEEDED weights -- the harness is what is measured, not the method): " + json.dumps(summ["bd"]) + "\n")
