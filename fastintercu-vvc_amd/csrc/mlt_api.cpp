@@ -1326,10 +1326,16 @@ struct CalibSession {
     st.calib_max = P.max;
     return MLT_OK;
   }
-  // The configuration price() has just measured, behind the MAGNITUDE guard: threshold = where its worst relative error reaches max_frac x
-  // tolerance, figures over the CUs at or below it (main set + the in-distribution set, which is staged -- and its exact logits computed -- on first use).
+  // The configuration price() has just measured, behind the MAGNITUDE guard.  Threshold: the LARGEST magnitude T on a quarter-octave grid (from the
+  // largest magnitude in the sets downwards) such that the CUs with M <= T -- main set + the in-distribution set, which is staged, and its exact
+  // logits computed, on first use -- meet the REFINED admission rule (mlt_tier_search.h: k x rms <= 0.95 x and max <= 0.6 x tolerance: the rule for
+  // choices made on the calibration data itself) with at least kGuardMinKept CUs left and at most flag_max of the in-distribution CUs above T.
+  // The rule is the plain one applied to the population that will really run the tier -- the logic of the flat-content guard ("content the guard
+  // catches does not count") with the threshold found instead of fixed.  (A first form derived T from the worst RELATIVE error over all CUs,
+  // T = 0.65 x tolerance / max(e / M): it charged ordinary content for the relative error of the constant-band classes -- 4 x the others' -- and
+  // flagged 9 % of it where the kept CUs' largest error was a quarter of the limit: profiles/r06b_calib_trained1.txt.)
   static constexpr int kGuardMinKept = 256;
-  int price_guarded(unsigned mask, unsigned xmask, float max_frac, float tolerance, mlt::TierPrice &out) {
+  int price_guarded(unsigned mask, unsigned xmask, const mlt::TierRules &R, mlt::TierPrice &out) {
     out.g_valid = false;
     if (!want_mag || main.mag.size() != (size_t)main.n) return MLT_OK;
     int rc;
@@ -1347,44 +1353,49 @@ struct CalibSession {
       if ((rc = run(xtra, xtra.le, true, 0, 0, nullptr, true))) return rc;
     }
     if ((rc = run(xtra, xtra.lf, false, mask, xmask))) return rc;
-    const int nl = st.model.n_logits;
     const Set *sets[2] = {&main, &xtra};
-    // worst relative error |dlogit| / magnitude over EVERY CU that counts (whatever its magnitude: this is the model the guard extrapolates)
-    double rel = 0.0;
+    float m_hi = 0.f, m_lo = INFINITY;
+    int in_dist = 0;
     for (const Set *T : sets)
       for (int i = 0; i < T->n; ++i) {
         if (!T->use[(size_t)i]) continue;
-        const double m = T->mag[(size_t)i];
-        double e = 0.0;
-        for (int j = 0; j < nl; ++j) { const double d = std::fabs((double)T->lf[(size_t)i * nl + j] - (double)T->le[(size_t)i * nl + j]); if (!(d <= e)) e = d; }
-        if (!(m > 0.0) || !(e == e)) { if (e != 0.0) rel = INFINITY; continue; }
-        if (e / m > rel) rel = e / m;
-      }
-    if (!(rel > 0.0) || !std::isfinite(rel)) return MLT_OK;
-    const float thr = (float)((double)max_frac * (double)tolerance / rel);
-    TierPrice_ P;
-    int kept = 0;
-    pool(sets, 2, thr, P, &kept);
-    // the guard's price on ordinary content: the in-distribution CUs (texture, 1/f scenes, the caller's own) it sends to the exact re-run
-    int in_dist = 0, flagged = 0;
-    for (const Set *T : sets)
-      for (int i = 0; i < T->n; ++i) {
+        const float m = T->mag[(size_t)i];
+        if (!(m > 0.f) || !std::isfinite(m)) return MLT_OK;   // (a NaN / zero magnitude: no guarded variant)
+        if (m > m_hi) m_hi = m;
+        if (m < m_lo) m_lo = m;
         const int c = T->cls[(size_t)i];
-        if (!T->use[(size_t)i] || !(c == 0 || c == kCalibClasses || c == kClassScenes)) continue;
-        ++in_dist;
-        if (!(T->mag[(size_t)i] <= thr)) ++flagged;
+        if (c == 0 || c == kCalibClasses || c == kClassScenes) ++in_dist;
       }
-    out.g_valid = kept >= kGuardMinKept && in_dist > 0;
-    out.g_rms = P.rms; out.g_max = P.max; out.g_tail = P.tail; out.g_thr = thr; out.g_flag = in_dist ? (float)flagged / (float)in_dist : 1.f;
-    last_rel = (float)rel;
-    if (std::getenv("MLT_CALIB_VERBOSE")) {
-      std::fprintf(stderr, "mltcnn calibration, behind the magnitude guard (worst relative error %.3e -> threshold %.3f; %d CUs at or below it, %d of %d in-distribution CUs above): rms per class",
-                   rel, (double)thr, kept, flagged, in_dist);
-      for (int c = 0; c < kCalibClasses + 2; ++c) std::fprintf(stderr, " %.3e", P.cls_rms[c]);
-      std::fprintf(stderr, " | per head");
-      for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", P.head_rms[h]);
-      std::fprintf(stderr, " | max %.3e = %.1f x rms\n", (double)P.max, (double)P.tail);
+    if (!(m_hi > 0.f) || in_dist == 0) return MLT_OK;
+    const bool verbose = std::getenv("MLT_CALIB_VERBOSE") != nullptr;
+    for (float thr = m_hi * 0.840896415f; thr >= m_lo; thr *= 0.840896415f) {   // 2^(-1/4) per step; T = m_hi would be the plain rule again
+      TierPrice_ P;
+      int kept = 0;
+      pool(sets, 2, thr, P, &kept);
+      if (kept < kGuardMinKept) break;
+      mlt::TierPrice tp;
+      tp.rms = P.rms; tp.max = P.max; tp.tail = P.tail;
+      if (!R.within_refined(tp)) continue;
+      // the guard's price on ordinary content: the in-distribution CUs (texture, 1/f scenes, the caller's own) it sends to the exact re-run
+      int flagged = 0;
+      for (const Set *T : sets)
+        for (int i = 0; i < T->n; ++i) {
+          const int c = T->cls[(size_t)i];
+          if (T->use[(size_t)i] && (c == 0 || c == kCalibClasses || c == kClassScenes) && !(T->mag[(size_t)i] <= thr)) ++flagged;
+        }
+      out.g_valid = true;
+      out.g_rms = P.rms; out.g_max = P.max; out.g_tail = P.tail; out.g_thr = thr; out.g_flag = (float)flagged / (float)in_dist;
+      if (verbose) {
+        std::fprintf(stderr, "mltcnn calibration, behind the magnitude guard (threshold %.3f of %.3f .. %.3f: %d CUs at or below it, %d of %d in-distribution CUs above): rms per class",
+                     (double)thr, (double)m_lo, (double)m_hi, kept, flagged, in_dist);
+        for (int c = 0; c < kCalibClasses + 2; ++c) std::fprintf(stderr, " %.3e", P.cls_rms[c]);
+        std::fprintf(stderr, " | per head");
+        for (int h = 0; h < st.model.n_heads; ++h) std::fprintf(stderr, " %.3e", P.head_rms[h]);
+        std::fprintf(stderr, " | max %.3e = %.1f x rms\n", (double)P.max, (double)P.tail);
+      }
+      return MLT_OK;
     }
+    if (verbose) std::fprintf(stderr, "mltcnn calibration, behind the magnitude guard: no threshold in %.3f .. %.3f meets the refined rule with >= %d CUs\n", (double)m_lo, (double)m_hi, kGuardMinKept);
     return MLT_OK;
   }
   float last_rel = 0.f;
@@ -1426,7 +1437,7 @@ struct DevicePricer : mlt::TierPricer {
     if ((rc = cal.price(w2_units, x_units))) return rc;
     out.rms = st.calib_rms; out.max = st.calib_max; out.tail = cal.tail_ratio;
     // (the refined rule is the stricter of the two: whatever the search is about to test, a configuration that fails it gets its guarded figures)
-    if (rules && cal.want_mag && !rules->within_refined(out) && (rc = cal.price_guarded(w2_units, x_units, rules->max_frac, rules->tolerance, out))) return rc;
+    if (rules && cal.want_mag && !rules->within_refined(out) && (rc = cal.price_guarded(w2_units, x_units, *rules, out))) return rc;
     return MLT_OK;
   }
   int price_lite(mlt::TierPrice &out) override {
@@ -1555,7 +1566,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
         st.w2_mask = mlt::stages_of_units(ch.w2_units); st.x_mask = mlt::stages_of_units(ch.x_units);
         if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
         st.mag_thr = ch.mag_thr; st.mag_flag = ch.mag_flag;   // > 0: the tier was admitted behind the magnitude guard
-        st.calib_rel = ch.mag_thr > 0.f ? rules.max_frac * rules.tolerance / ch.mag_thr : 0.f;
+        st.calib_rel = ch.mag_thr > 0.f ? ch.price.max / ch.mag_thr : 0.f;
       }
     }
   }

@@ -20,11 +20,11 @@ struct TierPrice {
   float max = 0.f;   // largest |dlogit| over the calibration logits
   float tail = 0.f;  // max / (rms pooled over everything)
   // Round 6 -- the same configuration behind the MAGNITUDE guard (mlt_api.cpp, "magnitude guard"): the pricer fills these when the plain
-  // figures above miss the contract and it has such a guard.  g_thr = the magnitude up to which the configuration's worst RELATIVE error
-  // (|dlogit| / magnitude, over every calibration CU) stays within max_frac x tolerance; CUs above it are re-evaluated exactly at run time, so
-  // g_rms / g_max / g_tail are the figures over the CUs at or below it -- the synthetic set's, the caller's, and a further in-distribution set
-  // (texture + 1/f scenes) that restores the sample size; g_flag = the fraction of the in-distribution CUs above the threshold (the price
-  // of the guard on ordinary content: each costs an exact re-run).
+  // figures above miss the contract and it has such a guard.  g_thr = the largest logit magnitude (quarter-octave grid) up to which the
+  // calibration CUs meet the REFINED rule; CUs above it are re-evaluated exactly at run time, so g_rms / g_max / g_tail are the figures over
+  // the CUs at or below it -- the synthetic set's, the caller's, and a further in-distribution set (texture + 1/f scenes) that restores the
+  // sample size; g_flag = the fraction of the in-distribution CUs above the threshold (the price of the guard on ordinary content: each
+  // costs an exact re-run).
   bool g_valid = false;
   float g_rms = 0.f, g_max = 0.f, g_tail = 0.f, g_thr = 0.f, g_flag = 0.f;
   TierPrice guarded() const { TierPrice p; p.rms = g_rms; p.max = g_max; p.tail = g_tail; return p; }

@@ -167,9 +167,11 @@ typedef struct mlt_arith_info {
    * part of the logits (the head's poc / qp / bias terms are exact).  A weight set that amplifies content far outside its training range -- a
    * residual plane of hundreds of ten-bit steps -- produces logits and absolute errors 20-80 x those of ordinary content there; such a set is
    * admitted to a non-exact tier BEHIND this guard: CUs with M > mag_guard_thr are re-evaluated with the exact arithmetic (third guard beside
-   * the flat-content and the decision guard, same re-run path, counted in guard_reruns).  The threshold is where the tier's worst relative error
-   * measured at load time reaches 0.65 x tolerance; the admission figures (calib_rms / calib_max) are then those of the calibration CUs at or
-   * below it, including 320 further in-distribution CUs (texture + 1/f scenes).  0: the tier was admitted by the plain rule, no such guard. */
+   * the flat-content and the decision guard, same re-run path, counted in guard_reruns).  The threshold is the largest magnitude (on a
+   * quarter-octave grid) up to which the calibration CUs -- the 560 synthetic ones, the caller's, and 320 further in-distribution CUs (texture +
+   * 1/f scenes) -- meet the admission rule in its stricter "refinement" form (5.5 .. 6.5 x rms <= 0.95 x, max <= 0.6 x tolerance) with at most
+   * 5 % of the in-distribution CUs above it; calib_rms / calib_max are the figures of the CUs at or below it.  0: the tier was admitted by the
+   * plain rule, no such guard. */
   float mag_guard_thr;
   float mag_guard_flagged;  /* fraction of the in-distribution calibration CUs (texture, 1/f scenes, the caller's) above the threshold: what the guard costs on ordinary content */
 } mlt_arith_info;

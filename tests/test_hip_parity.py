@@ -165,7 +165,9 @@ def test_tails_of_the_shipped_tier_on_a_large_sample(gpu, seed):
     blob = pkg.weights.synthetic_blob(0, seed)
     m = _ctx(pkg, size, blob)
     e = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128)
-    assert m.arithmetic(size)["exact"] == {10: 0, 23: 0, 11: 3, 21: 4}[seed]
+    # (seed 21, round 6: hi+lo weights in three stages behind the magnitude guard instead of an exact stage -- the plain rule had rejected it on ONE
+    # outlier of 5040 logits, max 6.9e-4 = 5.9 x rms, and the outlier's CU has the set's largest logit magnitude)
+    assert m.arithmetic(size)["exact"] in {10: (0,), 23: (0,), 11: (3,), 21: (3, 4)}[seed]
     assert m.arithmetic(size)["rounding"] != 0 if seed == 23 else m.arithmetic(size)["rounding"] in range(6)   # (seed 10 keeps the default, the sets in lower tiers the realisation that came closest)
     assert seed != 10 or m.arithmetic(size)["rounding"] == 0
     worst = 0.0
@@ -365,7 +367,7 @@ def test_load_time_calibration_picks_the_arithmetic(gpu):
     tight = _ctx(pkg, size, b10, tolerance=2e-4)
     a = tight.arithmetic(size)
     print("tolerance 2e-4:", a)
-    assert a["exact"] == 5 and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 2e-4 and a["calib_max"] <= 0.65 * 2e-4 and a["flat_guard"] == 0 and a["decision_guard"] == 1
+    assert a["exact"] == 5 and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 2e-4 and a["calib_max"] <= 0.65 * 2e-4 and a["flat_guard"] == 1 and a["decision_guard"] == 1   # (round 6: the tier keeps the flat guard, at 1/16)
     sl3, ll3 = tight.predict_batch(org, pred, poc, qp)
     r10, r10s = oracle.Oracle(b10).forward(org, pred, poc, qp)
     assert np.abs(ll3 - r10).max() <= 2e-4 and np.array_equal(sl3, r10s)
@@ -399,7 +401,7 @@ def test_middle_tier_hi_lo_weights(gpu):
         m = _ctx(pkg, size, blob)
         a = m.arithmetic(size)
         print(f"seed {seed}:", a)
-        assert a["exact"] in ((4,) if seed in (21, 22) else (2, 3)) and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.65e-3 and a["flat_guard"] == 1
+        assert a["exact"] in ((4,) if seed == 22 else (3, 4) if seed == 21 else (2, 3)) and a["calibrated"] == 1 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.65e-3 and a["flat_guard"] == 1
         assert (a["x_stages"] != 0) == (a["exact"] == 4) and (a["x_units"] & a["w2_units"]) == 0
         # (launch-unit granularity: a stage counts as hi+lo weights when at least one of its two units is)
         assert a["w2_stages"] == sum(1 << st for st in range(4) if (a["w2_units"] >> (2 * st)) & 3)
