@@ -65,7 +65,8 @@ struct SizeState {
                                // model (two activation planes, FP8 cross terms; mlt_model.h: xl), the flat guard is off (its error is 1/20 of the single
                                // pass's), the decision guard -- if configured -- still re-evaluates near-ties with `model_exact`
   bool cfg_flat_guard = false; // flat guard as configured (flags); flat_guard is what the loaded tier uses
-  int flat_div = 8;            // the flat guard re-evaluates a CU when >= 1 / flat_div of its quads are EXACTLY flat.  8 for the fp16 tiers; 16 for the exact-lite
+  int flat_div = 8;            // the flat guard re-evaluates a CU when >= 1 / flat_div of its quads are EXACTLY flat.  8 for the fp16 tiers admitted by the plain rule; 16
+                               // for a tier behind the magnitude guard (CalibSession::price_guarded) and for the exact-lite
                                // tier (round 6: its FP8 cross terms quantise a constant area's activations coherently -- 3-bit mantissas -- and a weight set with
                                // large logits turns a 10-12 % constant band into |dlogit| 1.0-1.5e-3: 4 of 331,776 probed logits of the second trained family,
                                // profiles/r06b_tail_probe_trained.txt; round 5 had switched the guard OFF for this tier on the strength of the seeded sets)
@@ -496,7 +497,8 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
                              (double)n * 128 * 128 * 4 + (px / 4) * 64 * 2 * 2, e0, e1)
               : L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, grid_x, ctx->stream));
+  static const bool mfma32 = tuning_env("MLT_L0_MFMA32") != nullptr;   // round 5's MFMA shape (A/B; the results are the same bits)
+  HIP_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (c5) {
     if ((rc = debug_dump(ctx, "conv3x3_s2_32to64_h32+sc", y_t, (size_t)(px / 4) * 64 * 2))) return rc;
@@ -587,7 +589,8 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin("layer1_stream_h32(conv2+conv1+conv2)", 3.0 * 2.0 * px * 64 * 64 * 9, px * 64 * 2 * 3 + 3.0 * 72 * 1024, e0, e1);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_layer1_stream(a, grid_x, ctx->stream));
+  static const bool mfma32 = tuning_env("MLT_L1_MFMA32") != nullptr;   // round 5's MFMA shape (A/B; the results are the same bits)
+  HIP_TRY(ctx, mlt_launch_layer1_stream(a, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, "chain3_s1_64_h32(conv2+conv1+conv2)", y, (size_t)px * 64 * 2);
 }
@@ -1266,7 +1269,7 @@ struct CalibSession {
   }
   struct TierPrice_ { float rms = 0.f, max = 0.f, tail = 0.f; double cls_rms[kCalibClasses + 2] = {0}, head_rms[4] = {0}; };
   // pooled figures of (candidate - exact) over the CUs of `sets` that count and whose magnitude is <= thr (thr <= 0: all of them)
-  void pool(const Set *const *sets, int n_sets, float thr, TierPrice_ &out, int *n_kept = nullptr) {
+  void pool(const Set *const *sets, int n_sets, float thr, TierPrice_ &out, int *n_kept = nullptr, const std::vector<char> *const *masks = nullptr) {
     const int nl = st.model.n_logits;
     double mx = 0.0, s2_all = 0.0;
     double s2_cls[kCalibClasses + 2] = {0}, s2_head[4] = {0};
@@ -1274,8 +1277,9 @@ struct CalibSession {
     int kept = 0;
     for (int t = 0; t < n_sets; ++t) {
       const Set &T = *sets[t];
+      const std::vector<char> &use = masks ? *masks[t] : T.use;
       for (int i = 0; i < T.n; ++i) {
-        if (!T.use[(size_t)i]) continue;
+        if (!use[(size_t)i]) continue;
         if (thr > 0.f && !(T.mag[(size_t)i] <= thr)) continue;
         ++kept;
         int lo = 0;
@@ -1354,11 +1358,22 @@ struct CalibSession {
     }
     if ((rc = run(xtra, xtra.lf, false, mask, xmask))) return rc;
     const Set *sets[2] = {&main, &xtra};
+    // A tier behind the magnitude guard also runs the FLAT guard at 1 / 16 of the quads exactly flat instead of 1 / 8 (SizeState.flat_div): the weight
+    // sets that need this guard are the ones whose errors grow with what they amplify, and a 10-12 % constant band -- just under 1 / 8 -- was the one class
+    // whose deep tail left the contract behind the guard (5 of 331,776 probed logits of the first trained family at 1.0-1.35e-3, all in that class:
+    // profiles/r06d_tail_probe_trained.txt; 80 such CUs in the calibration set do not see a 1-in-7000 event).  The CUs THAT guard takes do not count here.
+    if (use16[0].empty()) {
+      use16[0] = main.use; use16[1] = xtra.use;
+      if ((rc = drop_flat(main, 0, 16, &use16[0]))) return rc;
+      if ((rc = drop_flat(xtra, 0, 16, &use16[1]))) return rc;
+    }
+    const std::vector<char> *masks[2] = {&use16[0], &use16[1]};
     float m_hi = 0.f, m_lo = INFINITY;
     int in_dist = 0;
-    for (const Set *T : sets)
+    for (int t = 0; t < 2; ++t) {
+      const Set *T = sets[t];
       for (int i = 0; i < T->n; ++i) {
-        if (!T->use[(size_t)i]) continue;
+        if (!use16[t][(size_t)i]) continue;
         const float m = T->mag[(size_t)i];
         if (!(m > 0.f) || !std::isfinite(m)) return MLT_OK;   // (a NaN / zero magnitude: no guarded variant)
         if (m > m_hi) m_hi = m;
@@ -1366,23 +1381,26 @@ struct CalibSession {
         const int c = T->cls[(size_t)i];
         if (c == 0 || c == kCalibClasses || c == kClassScenes) ++in_dist;
       }
+    }
     if (!(m_hi > 0.f) || in_dist == 0) return MLT_OK;
     const bool verbose = std::getenv("MLT_CALIB_VERBOSE") != nullptr;
     for (float thr = m_hi * 0.840896415f; thr >= m_lo; thr *= 0.840896415f) {   // 2^(-1/4) per step; T = m_hi would be the plain rule again
       TierPrice_ P;
       int kept = 0;
-      pool(sets, 2, thr, P, &kept);
+      pool(sets, 2, thr, P, &kept, masks);
       if (kept < kGuardMinKept) break;
       mlt::TierPrice tp;
       tp.rms = P.rms; tp.max = P.max; tp.tail = P.tail;
       if (!R.within_refined(tp)) continue;
       // the guard's price on ordinary content: the in-distribution CUs (texture, 1/f scenes, the caller's own) it sends to the exact re-run
       int flagged = 0;
-      for (const Set *T : sets)
+      for (int t = 0; t < 2; ++t) {
+        const Set *T = sets[t];
         for (int i = 0; i < T->n; ++i) {
           const int c = T->cls[(size_t)i];
-          if (T->use[(size_t)i] && (c == 0 || c == kCalibClasses || c == kClassScenes) && !(T->mag[(size_t)i] <= thr)) ++flagged;
+          if (use16[t][(size_t)i] && (c == 0 || c == kCalibClasses || c == kClassScenes) && !(T->mag[(size_t)i] <= thr)) ++flagged;
         }
+      }
       out.g_valid = true;
       out.g_rms = P.rms; out.g_max = P.max; out.g_tail = P.tail; out.g_thr = thr; out.g_flag = (float)flagged / (float)in_dist;
       if (verbose) {
@@ -1398,7 +1416,7 @@ struct CalibSession {
     if (verbose) std::fprintf(stderr, "mltcnn calibration, behind the magnitude guard: no threshold in %.3f .. %.3f meets the refined rule with >= %d CUs\n", (double)m_lo, (double)m_hi, kGuardMinKept);
     return MLT_OK;
   }
-  float last_rel = 0.f;
+  std::vector<char> use16[2];   // main / xtra: the CUs that count behind the flat guard at 1 / 16
 };
 
 void drop_graphs(mlt_ctx *ctx, int si) {  // a captured kernel chain bakes in weight / workspace pointers
@@ -1566,6 +1584,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
         st.w2_mask = mlt::stages_of_units(ch.w2_units); st.x_mask = mlt::stages_of_units(ch.x_units);
         if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
         st.mag_thr = ch.mag_thr; st.mag_flag = ch.mag_flag;   // > 0: the tier was admitted behind the magnitude guard
+        if (st.mag_thr > 0.f) st.flat_div = 16;               // ... and then runs the flat guard at 1 / 16 (CalibSession::price_guarded)
         st.calib_rel = ch.mag_thr > 0.f ? ch.price.max / ch.mag_thr : 0.f;
       }
     }

@@ -241,6 +241,6 @@ bool mlt_conv_cfg(int cin, int cout, int stride, int exact, ConvCfg *out);
 hipError_t mlt_launch_stem5(const Stem5Args &a, int nsplit, int grid_x, int lds, hipStream_t st);  // nsplit as mlt_launch_conv
 hipError_t mlt_launch_block32(const Block32Args &a, bool w2, int grid_x, hipStream_t st);     // w2: hi+lo weights (8 x 32 tiles)
 hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hipStream_t st);
-hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x, hipStream_t st);
-hipError_t mlt_launch_layer1_stream(const Layer1Args &a, int grid_x, hipStream_t st);
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, bool mfma32, int grid_x, hipStream_t st);
+hipError_t mlt_launch_layer1_stream(const Layer1Args &a, bool mfma32, int grid_x, hipStream_t st);
 hipError_t mlt_launch_heads(const HeadArgs &a, int n, hipStream_t st);

@@ -253,7 +253,7 @@ __device__ __forceinline__ void unpair16(uint4v v, half4 &qa, half4 &qb) {  // i
 // The ReLU is applied AFTER the rounding: max(0, .) commutes with a monotonic rounding, so the values are those of fmaxf before it.
 // x4 (optional) receives the fp32 values before the ReLU (GAP sums).
 typedef float float2v __attribute__((ext_vector_type(2)));
-template <int Q> __device__ __forceinline__ half4 act_quad(const float16v &A, float scale, const float4v &b, bool has_res, const half4 &r, bool relu, float *x4 = nullptr) {
+template <int Q, class ACC = float16v> __device__ __forceinline__ half4 act_quad(const ACC &A, float scale, const float4v &b, bool has_res, const half4 &r, bool relu, float *x4 = nullptr) {
   half4 out;
 #pragma unroll
   for (int ep = 0; ep < 2; ++ep) {
@@ -790,22 +790,27 @@ hipError_t mlt_launch_stem_block(const StemBlockArgs &a, bool w2, int grid_x, hi
   return hipGetLastError();
 }
 
-hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, int grid_x, hipStream_t st) {
-  static DeviceOnce once[2];
-  if (fuse5) {  // + layer1's stride-2 conv and shortcut as a fifth stage
-    if (hipError_t e = ensure_big_lds(layer0_stream_kernel<true>, once[1]); e != hipSuccess) return e;
-    hipLaunchKernelGGL(layer0_stream_kernel<true>, dim3(grid_x), dim3(1024), MLT_L0F_LDS_BYTES, st, a);
-    return hipGetLastError();
-  }
-  if (hipError_t e = ensure_big_lds(layer0_stream_kernel<false>, once[0]); e != hipSuccess) return e;
-  hipLaunchKernelGGL(layer0_stream_kernel<false>, dim3(grid_x), dim3(1024), MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot: 4 stages x 4 row units
+template <bool F5, bool M16> static hipError_t launch_layer0_stream_t(const Layer0Args &a, int grid_x, hipStream_t st) {
+  static DeviceOnce once;
+  if (hipError_t e = ensure_big_lds(layer0_stream_kernel<F5, M16>, once); e != hipSuccess) return e;
+  hipLaunchKernelGGL((layer0_stream_kernel<F5, M16>), dim3(grid_x), dim3(1024), F5 ? MLT_L0F_LDS_BYTES : MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot
   return hipGetLastError();
 }
+// fuse5: + layer1's stride-2 conv and shortcut as a fifth stage; mfma32: round 5's MFMA shape (MLT_TUNING=1 MLT_L0_MFMA32=1: same-box A/B; same bits)
+hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, bool mfma32, int grid_x, hipStream_t st) {
+  if (fuse5) return mfma32 ? launch_layer0_stream_t<true, false>(a, grid_x, st) : launch_layer0_stream_t<true, true>(a, grid_x, st);
+  return mfma32 ? launch_layer0_stream_t<false, false>(a, grid_x, st) : launch_layer0_stream_t<false, true>(a, grid_x, st);
+}
 
-hipError_t mlt_launch_layer1_stream(const Layer1Args &a, int grid_x, hipStream_t st) {
-  static DeviceOnce once;
-  if (hipError_t e = ensure_big_lds(layer1_stream_kernel, once); e != hipSuccess) return e;
-  hipLaunchKernelGGL(layer1_stream_kernel, dim3(grid_x), dim3(1024), MLT_L1_LDS_BYTES, st, a);
+hipError_t mlt_launch_layer1_stream(const Layer1Args &a, bool mfma32, int grid_x, hipStream_t st) {
+  static DeviceOnce once[2];
+  if (mfma32) {  // round 5's form on v_mfma_f32_32x32x16_f16 (MLT_TUNING=1 MLT_L1_MFMA32=1: same-box A/B; same bits)
+    if (hipError_t e = ensure_big_lds(layer1_stream_kernel<false>, once[0]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(layer1_stream_kernel<false>, dim3(grid_x), dim3(1024), MLT_L1_LDS_BYTES, st, a);
+    return hipGetLastError();
+  }
+  if (hipError_t e = ensure_big_lds(layer1_stream_kernel<true>, once[1]); e != hipSuccess) return e;
+  hipLaunchKernelGGL(layer1_stream_kernel<true>, dim3(grid_x), dim3(1024), MLT_L1_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

@@ -106,10 +106,12 @@ def test_layer0_stream_kernel_keeps_its_raw_prefetch_counted_and_its_step_loops_
     assert len(counted) >= 4, f"S1's raw-row waits are no longer counted: {inner}"
 
 
-def test_layer1_stream_kernel_fits_its_waves_without_scratch(stats):
+@pytest.mark.parametrize("form", ("true", "false"))
+def test_layer1_stream_kernel_fits_its_waves_without_scratch(stats, form):
     """layer1_stream_kernel (round 5): twelve conv waves with 18 resident A fragments each, at 128 VGPRs -- no spills (a reload in a row loop is a
-    vector-memory round trip per row), and its loader waves' waits are counted."""
-    st = _find(stats, "layer1_stream_kernel")
+    vector-memory round trip per row), and its loader waves' waits are counted.  Both MFMA shapes (round 6: <true> = v_mfma_f32_16x16x32_f16, the
+    default; <false> = round 5's 32x32x16)."""
+    st = _find(stats, f"layer1_stream_kernel<{form}>")
     assert st["scratch"] == 0, f"{st['scratch']} scratch ops"
     drains = [w for w in st["waits"] if w[1] >= 1 and "vmcnt(0)" in w[2]]
     assert len(drains) <= 3, f"compiler drains inside loops: {drains}"   # two beside the LDS-clearing loop at the top, one at the end of the loaders' step group
