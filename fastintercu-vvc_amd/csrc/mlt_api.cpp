@@ -191,6 +191,10 @@ struct mlt_ctx {
   bool lds_oob_zero = false;  // DS reads beyond the LDS allocation return zeros on this device (probed at init): chain kernels without zero masks
   std::map<std::string, ProfAcc> prof;
   std::vector<std::string> prof_order;
+  // Round 6: != NULL = PLAN mode -- the dispatcher (run_network and the run_* functions under it) runs its decisions as usual but
+  // RECORDS every launch (name + variant) here instead of enqueuing it, touches no device and allocates nothing: what a batch of n CUs of a tier
+  // would launch, observable and unit-tested on the CPU (mlt_plan_describe, tests/test_launch_plan_cpu.py).
+  std::vector<std::string> *plan = nullptr;
 };
 
 namespace {
@@ -203,6 +207,9 @@ namespace {
       return MLT_ERR_HIP;                                                                              \
     }                                                                                                  \
   } while (0)
+
+// a kernel launch of the dispatcher: skipped in plan mode (the launch was recorded by Launch::prof_begin)
+#define LAUNCH_TRY(ctx, expr) do { if (!(ctx)->plan) HIP_TRY(ctx, expr); } while (0)
 
 int upload_model(mlt_ctx *ctx, mlt::Model &m) {
   auto up = [&](mlt::PackedConv &pc) -> int {
@@ -299,7 +306,8 @@ int debug_dump(mlt_ctx *ctx, const char *name, const void *dptr, size_t bytes) {
 
 struct Launch {
   mlt_ctx *ctx;
-  int prof_begin(const std::string &name, double flops, double bytes, hipEvent_t &e0, hipEvent_t &e1) {
+  int prof_begin(const std::string &name, double flops, double bytes, hipEvent_t &e0, hipEvent_t &e1, const char *variant = nullptr) {
+    if (ctx->plan) { ctx->plan->push_back(variant && variant[0] ? name + " [" + variant + "]" : name); return MLT_OK; }
     if (!ctx->profile) return MLT_OK;
     auto it = ctx->prof.find(name);
     if (it == ctx->prof.end()) { ctx->prof_order.push_back(name); it = ctx->prof.emplace(name, ProfAcc()).first; }
@@ -408,9 +416,13 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   const double bytes = in_bytes + px * pc.cout * 2 * ((io.y ? 1 : 0) + (io.y_sc ? 1 : 0) + (io.res ? 1 : 0)) + (double)pc.w.size() * 2;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin(name, flops, bytes, e0, e1);
+  char variant[96];
+  std::snprintf(variant, sizeof variant, "%s%s%s%s%s", nsplit == 1 ? "single pass" : nsplit == 2 ? "exact" : nsplit == 4 ? "hi+lo weights" : nsplit == 6 ? "exact-lite" : "?",
+                pc.taps == 1 ? ", centre tap" : lat ? ", latency tiles" : dma == 1 ? ", resident weights + LDS-DMA patches" : dma == 2 ? ", weight ring + LDS-DMA" : "",
+                io.y_c16 ? ", y chunk-major" : "", io.ysc_c16 ? ", sc chunk-major" : "", io.gap ? ", GAP" : "");
+  int rc = L.prof_begin(name, flops, bytes, e0, e1, variant);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, nsplit, pc.taps == 1 ? MLT_CONV_CENTRE : lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, nsplit, pc.taps == 1 ? MLT_CONV_CENTRE : lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
   if (io.y_sc && (rc = debug_dump(ctx, (std::string(name) + "_sc").c_str(), io.y_sc, (size_t)px * pc.cout * 2))) return rc;
@@ -441,9 +453,9 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
   const double px = (double)n * hout * hout;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18), (double)n * S * S * 4 + px * 32 * 2 * 2, e0, e1);
+  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18), (double)n * S * S * 4 + px * 32 * 2 * 2, e0, e1, pc.xl ? "exact-lite" : pc.exact ? "exact" : pc.w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_stem5(a, pc.exact ? 2 : pc.w2 ? 3 : 1, grid_x, lds, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_stem5(a, pc.exact ? 2 : pc.w2 ? 3 : 1, grid_x, lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if ((rc = debug_dump(ctx, name, y, (size_t)px * 32 * 2))) return rc;
   return debug_dump(ctx, (std::string(name) + "_sc").c_str(), y_sc, (size_t)px * 32 * 2);
@@ -459,7 +471,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   a.w = m.stem_b.d_w; a.w2 = c2.d_w; a.bias = m.stem.d_bias; a.bias_sc = m.stem.d_bias_sc; a.bias2 = c2.d_bias; a.y = y;
   a.flat = d_flat;
   a.w_lo_off = m.stem_b.plane_halves * 2; a.w2_lo_off = c2.plane_halves * 2; a.scale2 = c2.acc_scale;
-  if (d_flat && !flat_is_clear) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));  // (flat_is_clear: the consumer of the previous call left it zero)
+  if (d_flat && !flat_is_clear) LAUNCH_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));  // (flat_is_clear: the consumer of the previous call left it zero)
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
   static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
@@ -468,9 +480,9 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   const double px = (double)n * h * h;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18 + 288), (double)n * S * S * 4 + px * 32 * 2, e0, e1);
+  int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18 + 288), (double)n * S * S * 4 + px * 32 * 2, e0, e1, m.w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_stem_block(a, m.w2, grid_x, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_stem_block(a, m.w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
@@ -487,7 +499,7 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
   a.bias = m0.stem.d_bias; a.bias_sc = m0.stem.d_bias_sc; a.bias2 = c2.d_bias; a.bias3 = B1.conv1.d_bias; a.bias4 = B1.conv2.d_bias;
   a.y = y; a.flat = d_flat; a.acc_scale = m0.stem.acc_scale; a.n = n;
   if (c5) { a.w5 = c5->d_w; a.bias5 = c5->d_bias; a.bias5_sc = c5->d_bias_sc; a.scale5 = c5->acc_scale; a.y_t = y_t; a.y_sc = y_sc; }
-  if (d_flat && !flat_is_clear) HIP_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
+  if (d_flat && !flat_is_clear) LAUNCH_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
   static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP0"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
   const int grid_x = n > wg_cap ? wg_cap : n;
   const double px = (double)n * 64 * 64;
@@ -498,7 +510,7 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
               : L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
   static const bool mfma32 = tuning_env("MLT_L0_MFMA32") != nullptr;   // round 5's MFMA shape (A/B; the results are the same bits)
-  HIP_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, mfma32, grid_x, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (c5) {
     if ((rc = debug_dump(ctx, "conv3x3_s2_32to64_h32+sc", y_t, (size_t)(px / 4) * 64 * 2))) return rc;
@@ -521,9 +533,9 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   const double px = (double)n * h * h;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin(name, 2.0 * px * 32 * 32 * 9 * 2, px * 32 * 2 * 2 + 2.0 * 18 * 1024, e0, e1);
+  int rc = L.prof_begin(name, 2.0 * px * 32 * 32 * 9 * 2, px * 32 * 2 * 2 + 2.0 * 18 * 1024, e0, e1, w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_block32(a, w2, grid_x, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_block32(a, w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
 }
@@ -567,9 +579,12 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
                        (s2_in ? (double)B0.conv1_s2c.w.size() * 2 : 0.0);
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin(name, flops, bytes, e0, e1);
+  char variant[96];
+  std::snprintf(variant, sizeof variant, "%s%s%s%s%s", w2 ? "hi+lo weights" : "single pass", x_c16 ? ", x chunk-major" : "", sc_c16 ? ", sc chunk-major" : "", y_c16 ? ", y chunk-major" : "",
+                gap ? ", GAP" : "");
+  int rc = L.prof_begin(name, flops, bytes, e0, e1, variant);
   if (rc) return rc;
-  HIP_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, w2, a, grid_x, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, w2, a, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
   return MLT_OK;
@@ -587,10 +602,13 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
   const double px = (double)n * 32 * 32;
   Launch L{ctx};
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = L.prof_begin("layer1_stream_h32(conv2+conv1+conv2)", 3.0 * 2.0 * px * 64 * 64 * 9, px * 64 * 2 * 3 + 3.0 * 72 * 1024, e0, e1);
+  int rc = L.prof_begin("layer1_stream_h32(conv2+conv1+conv2)", 3.0 * 2.0 * px * 64 * 64 * 9, px * 64 * 2 * 3 + 3.0 * 72 * 1024, e0, e1, y_c16 ? "single pass, y chunk-major, GAP" : "single pass, GAP");
   if (rc) return rc;
-  static const bool mfma32 = tuning_env("MLT_L1_MFMA32") != nullptr;   // round 5's MFMA shape (A/B; the results are the same bits)
-  HIP_TRY(ctx, mlt_launch_layer1_stream(a, mfma32, grid_x, ctx->stream));
+  // round 6: the 16x16x32 MFMA form exists (same bits) but measures 2 % SLOWER here than round 5's 32x32x16 form (0.882 against 0.863 ms, same box, alternating:
+  // profiles/r06e_mfma16_ab.txt) -- the bare loop's +11 % is a clock effect at 1.6 GHz, this kernel already holds ~2.1 GHz and pays for twice the MFMA issue
+  // slots and 8-byte epilogue accesses: it stays on 32x32x16 (MLT_TUNING=1 MLT_L1_MFMA16=1 selects the other form)
+  static const bool mfma32 = tuning_env("MLT_L1_MFMA16") == nullptr;
+  LAUNCH_TRY(ctx, mlt_launch_layer1_stream(a, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, "chain3_s1_64_h32(conv2+conv1+conv2)", y, (size_t)px * 64 * 2);
 }
@@ -608,7 +626,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
                 mlt::Model *mx = nullptr, unsigned x_units = 0, float *d_mag = nullptr) {
   const int S = st.size;
   if (!mx) x_units = 0;
-  int rc = ensure_ws(ctx, ws_per_cu(m, S, x_units != 0) * (size_t)n);
+  int rc = ctx->plan ? MLT_OK : ensure_ws(ctx, ws_per_cu(m, S, x_units != 0) * (size_t)n);   // (plan mode: the workspace is carved from address 0 and never touched)
   if (rc) return rc;
   // carve the workspace
   char *p = ctx->ws;
@@ -654,7 +672,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   };
   // (the whole-stage form -- stride-2 conv + shortcut inside the launch -- exists for the single pass only: both units of the stage on `m`)
   auto wants_s2 = [&](int s, int h_in) -> bool {
-    return wants_chain(s, h_in) && !no_chain_s2 && !model_of(s, 0).w2 && !model_of(s, 1).w2 && model_of(s, 0).blocks[s][0].conv1_s2c.d_w != nullptr;
+    return wants_chain(s, h_in) && !no_chain_s2 && !model_of(s, 0).w2 && !model_of(s, 1).w2 && (ctx->plan ? !model_of(s, 0).blocks[s][0].conv1_s2c.w.empty() : model_of(s, 0).blocks[s][0].conv1_s2c.d_w != nullptr);
   };
   bool cur_c16 = false;  // layout of `cur`
   bool l0_did_s2 = false;  // the layer0 streaming launch carried layer1.0.conv1 + shortcut
@@ -689,7 +707,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       fa.pred_cu_stride = pred_cs; fa.flat = d_flat; fa.n = n; fa.s_l = ilog2(S);
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
-      HIP_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
+      LAUNCH_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
       if ((rc = L.prof_end(e1))) return rc;
     }
     // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups).
@@ -794,7 +812,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if ((rc = L.prof_begin("heads", 0.0, 0.0, e0, e1))) return rc;
-    HIP_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
+    LAUNCH_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
     if ((rc = L.prof_end(e1))) return rc;
   }
   return MLT_OK;
@@ -888,7 +906,7 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
   sa.near_thr = (S * S / 4) / 2;  // or >= 1/2 of them near-flat (mlt_kernels.h: MLT_FLAT_RANGE)
   sa.margin = st.margin_guard ? st.guard_margin : 0.f;
   if ((rc = L.prof_begin("guard_select", 0.0, 0.0, e0, e1))) return rc;
-  HIP_TRY(ctx, mlt_launch_guard_select(sa, ctx->stream));
+  LAUNCH_TRY(ctx, mlt_launch_guard_select(sa, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(g.h_count, g.d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
   return MLT_OK;
@@ -1662,6 +1680,43 @@ int mlt_calibrate(mlt_ctx *ctx, int size, const int16_t *org, const int16_t *pre
   rc = load_all(ctx, size, keep.data(), keep.size(), &ex);
   if (rc == MLT_OK) ctx->sz[size_index(size)].blob = std::move(keep);
   return rc;
+}
+
+// Host-only hook (not part of include/mltcnn.h; no HIP call, no device): the LAUNCH PLAN of one batch -- what run_network would enqueue for n CUs of `size`
+// with hi+lo weights in the launch units of w2_units and the exact arithmetic in those of x_units (tier: 0 the fp16 tiers as given by the two masks, 1 exact
+// everywhere, 5 exact-lite everywhere), planes 8-byte aligned or not.  The models are built from the blob on the host exactly as mlt_load_weights builds them;
+// the dispatcher then runs in plan mode (mlt_ctx::plan).  One launch per line: "name [variant, layouts]".  Returns the number of launches, or -1.
+int mlt_plan_describe(const void *blob, size_t bytes, int size, int n, int tier, unsigned w2_units, unsigned x_units, int aligned, char *out, size_t cap) {
+  const int si = size_index(size);
+  if (!blob || !out || cap == 0 || si < 0 || n <= 0) return -1;
+  mlt_ctx ctx;
+  std::vector<std::string> plan;
+  ctx.plan = &plan;
+  ctx.lds_oob_zero = true;    // (what every gfx950 device reports: mlt_probe_lds_oob)
+  SizeState &st = ctx.sz[si];
+  st.size = size; st.enabled = st.loaded = true;
+  st.head_index = size == 128 ? 2 : 0;
+  std::string err;
+  const bool whole_exact = tier == 1 || tier == 5;
+  if (!mlt::build_model(blob, bytes, tier == 5 ? mlt::MLT_MODEL_XLITE : tier == 1 ? mlt::MLT_MODEL_EXACT : mlt::MLT_MODEL_FAST, size, st.model, err)) return -1;
+  if (!whole_exact && w2_units && !mlt::build_model(blob, bytes, mlt::MLT_MODEL_W2, size, st.model_w2, err)) return -1;
+  if (!whole_exact && x_units && !mlt::build_model(blob, bytes, mlt::MLT_MODEL_EXACT, size, st.model_exact, err)) return -1;
+  st.exact = whole_exact;
+  st.w2 = !whole_exact && w2_units != 0; st.w2_units = st.w2 ? w2_units : 0; st.x_units = whole_exact ? 0 : x_units;
+  const long cs = (long)size * size;
+  const int16_t *planes = (const int16_t *)(uintptr_t)(aligned ? 0x1000 : 0x1002);   // never dereferenced: only the alignment is looked at
+  int32_t flat_dummy = 0;
+  const int rc = run_main(&ctx, st, n, planes, size, cs, planes, size, cs, nullptr, nullptr, nullptr, nullptr, whole_exact ? nullptr : &flat_dummy);
+  if (rc) return -1;
+  size_t pos = 0;
+  for (const std::string &l : plan) {
+    if (pos + l.size() + 2 > cap) return -1;
+    std::memcpy(out + pos, l.data(), l.size());
+    pos += l.size();
+    out[pos++] = '\n';
+  }
+  out[pos] = 0;
+  return (int)plan.size();
 }
 
 // Host-only hook (not part of include/mltcnn.h; no HIP call): the synthetic calibration set of a CU size, so that the numerics tools

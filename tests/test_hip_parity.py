@@ -147,7 +147,9 @@ def test_content_classes_against_oracle(gpu, seed):
     if tier != 1:  # the widened guard statistic really catches these classes (exact re-run of every CU)
         for k in ("dither", "low_contrast", "flat_zero_resi", "ramp"):
             assert report[(k, "default")][1] == n and report[(k, "no decision guard")][1] == n, (k, report[(k, "default")])
-        assert report[("partial_flat", "no decision guard")][1] == 0   # just UNDER the flat guard's threshold by construction: stays on the main arithmetic
+        # partial_flat sits just UNDER the flat guard's 1/8 by construction: it stays on the main arithmetic -- unless the tier was admitted behind the
+        # magnitude guard (round 6: seed 21), which runs the flat guard at 1/16 and therefore takes every one of these CUs
+        assert report[("partial_flat", "no decision guard")][1] == (n if m.arithmetic(size)["mag_guard_thr"] > 0 else 0)
     for _, c in ctxs:
         c.close()
 

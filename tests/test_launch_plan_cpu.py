@@ -1,0 +1,97 @@
+"""CPU: the dispatcher's LAUNCH PLANS.  run_network (csrc/mlt_api.cpp) decides, per batch, which kernels serve which launch units --
+tier x batch class x alignment x which neighbour is a whole-stage kernel (layouts between them) -- and round 5 left that decision observable only on a
+GPU.  The library's plan mode (mlt_ctx::plan) runs the same code with every launch RECORDED instead of enqueued; mlt_plan_describe (host-only hook, no
+device) returns the list.  Pinned here: the launches of the shipped tiers at the batch classes the encoder and the bench use, and the layout hand-offs
+(chunk-major outputs exactly where the consumer is a whole-stage kernel)."""
+import ctypes as C
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def plan(pkg):
+    pkg.build.build_lib()
+    lib = pkg.capi.load_library()
+    lib.mlt_plan_describe.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_size_t]
+    blobs = {}
+
+    def go(size, n, tier=0, w2_units=0, x_units=0, aligned=1, seed=10):
+        arch = pkg.synth.arch_for_size(size)
+        if (arch, seed) not in blobs:
+            blobs[(arch, seed)] = pkg.weights.synthetic_blob(arch, seed)
+        b = blobs[(arch, seed)]
+        buf = C.create_string_buffer(1 << 15)
+        k = lib.mlt_plan_describe(b, len(b), size, n, tier, w2_units, x_units, aligned, buf, 1 << 15)
+        lines = buf.value.decode().splitlines()
+        assert k == len(lines) and k > 0, (k, lines)
+        return lines
+    return go
+
+
+def names(lines):
+    return [l.split(" [")[0] for l in lines]
+
+
+def test_single_pass_batches_are_four_fused_launches_and_the_heads(plan):
+    p = plan(128, 4096)
+    assert names(p) == ["layer0_stream_h64(stem+layer0+layer1.0.conv1+sc)", "layer1_stream_h32(conv2+conv1+conv2)", "stage_128_h16(s2+sc,conv2,conv1,conv2)",
+                        "stage_256_h8(s2+sc,conv2,conv1,conv2)", "heads"]
+    # layouts: every producer of a whole-stage kernel's input writes chunk-major, the last stage writes no activation at all (GAP sums only)
+    assert "y chunk-major" in p[1] and "x chunk-major" in p[2] and "y chunk-major" in p[2] and "x chunk-major" in p[3] and "y chunk-major" not in p[3]
+    assert all("GAP" in l for l in p[1:4])
+    # round 6: the streaming launches start at 128 CUs (the measured crossover), not 256
+    assert names(plan(128, 128))[:2] == names(p)[:2]
+    assert names(plan(128, 127))[:4] == ["stem+block_s2_2to32_h64(layer0.0)", "block_s1_32_h64(conv1+conv2)", "conv3x3_s2_32to64_h32+sc", "chain3_s1_64_h32(conv2+conv1+conv2)"]
+
+
+def test_one_cu_call_runs_the_latency_variants(plan):
+    p = plan(128, 1)
+    assert len(p) == 15 and names(p)[:3] == ["stem+block_s2_2to32_h64(layer0.0)", "block_s1_32_h64(conv1+conv2)", "conv3x3_s2_32to64_h32+sc"]
+    assert all("latency tiles" in l for l in p[3:14]) and names(p)[-1] == "heads"
+    assert not any("chunk-major" in l for l in p)          # per-conv launches hand NHWC to each other
+    # 8 CUs (an N3 flush at 1080p): the same 15 launches
+    assert names(plan(128, 8)) == names(p)
+
+
+def test_hi_lo_weight_units_compose_with_the_single_pass_kernels(plan):
+    # layer1 in hi+lo weights (units 2, 3): the fifth stage stays out of the layer0 launch, the stride-2 conv and the 64-channel chain run their two-plane forms
+    p = plan(128, 4096, w2_units=0xC)
+    assert names(p) == ["layer0_stream_h64(stem+layer0.0+layer0.1)", "conv3x3_s2_32to64_h32+sc", "chain3_s1_64_h32(conv2+conv1+conv2)",
+                        "stage_128_h16(s2+sc,conv2,conv1,conv2)", "stage_256_h8(s2+sc,conv2,conv1,conv2)", "heads"]
+    assert "hi+lo weights" in p[1] and "hi+lo weights" in p[2] and "single pass" in p[3]
+    # layer2 in hi+lo weights: no whole-stage form there (the stride-2 conv is a launch of its own), so layer1 writes NHWC and layer2 chunk-major for layer3
+    p = plan(128, 4096, w2_units=0x30)
+    assert names(p)[2:4] == ["conv3x3_s2_64to128_h16+sc", "chain3_s1_128_h16(conv2+conv1+conv2)"]
+    assert "chunk-major" not in p[1] and "y chunk-major" in p[3] and "x chunk-major" in p[4]
+    # the first trained family's tier (round 6): hi+lo weights in layer0.0 and layer1's stride-2 conv, the streaming kernels on the rest
+    p = plan(128, 4096, w2_units=0x5)
+    assert names(p)[:4] == ["stem+block_s2_2to32_h64(layer0.0)", "block_s1_32_h64(conv1+conv2)", "conv3x3_s2_32to64_h32+sc", "layer1_stream_h32(conv2+conv1+conv2)"]
+    assert "hi+lo weights" in p[0] and "single pass" in p[1] and "hi+lo weights" in p[2]
+
+
+def test_exact_and_exact_lite_are_per_conv_launches(plan):
+    for tier, word in ((1, "exact"), (5, "exact-lite")):
+        p = plan(128, 4096, tier=tier)
+        assert len(p) == 17 and names(p)[0] == "stem5x5_s2_2to32_h64+sc" and names(p)[-1] == "heads"
+        assert all(f"[{word}" in l for l in p[1:16]), p
+    # an exact unit inside an fp16 tier: layer2 exact behind single-pass layer1 (the `exact = 4` tiers)
+    p = plan(128, 4096, x_units=0x30)
+    assert names(p)[:2] == ["layer0_stream_h64(stem+layer0+layer1.0.conv1+sc)", "layer1_stream_h32(conv2+conv1+conv2)"]
+    assert [("[exact" in l) for l in p[2:6]] == [True] * 4 and "stage_256" in p[6]
+
+
+def test_unaligned_planes_fall_back_to_the_two_step_front(plan):
+    """stem_block_kernel / layer0_stream_kernel fetch 4-pixel quads with 8-byte loads; planes that are not 8-byte aligned (a picture buffer at an odd
+    offset) run stem5_kernel + per-conv layer0.0 + block32 -- and the flat-content statistic comes from its own kernel."""
+    p = plan(128, 4096, aligned=0)
+    assert names(p)[:5] == ["guard_flat_stat", "stem5x5_s2_2to32_h64+sc", "conv3x3_s1_32to32_h64", "block_s1_32_h64(conv1+conv2)", "conv3x3_s2_32to64_h32+sc"]
+    assert names(p)[5:] == ["layer1_stream_h32(conv2+conv1+conv2)", "stage_128_h16(s2+sc,conv2,conv1,conv2)", "stage_256_h8(s2+sc,conv2,conv1,conv2)", "heads"]
+
+
+def test_small_models(plan):
+    p = plan(64, 4096, tier=1)
+    assert len(p) == 21 and all("[exact" in l for l in p[:20])
+    # the 16 x 16 model's calibrated tier: layer0 on the single pass, exact from layer1 on; 1 x 1 maps take the centre-tap kernels
+    p = plan(16, 4096, x_units=0x3FC)
+    assert names(p)[:2] == ["guard_flat_stat", "stem5x5_s2_2to32_h8+sc"] and all("single pass" in l for l in p[1:5]) and all("[exact" in l for l in p[5:21])
+    assert sum("centre tap" in l for l in p) == 7
