@@ -38,6 +38,46 @@ const char *tuning_env(const char *name) {
   return (e && e[0] == '1') ? std::getenv(name) : nullptr;
 }
 
+// Every tuning switch of the dispatcher and of the load path, parsed ONCE on first use (round 6, VERDICT r5 item 7: round 5 read them through some thirty
+// function-local statics scattered over the run_* functions).  All of them need MLT_TUNING=1 (tuning_env).
+struct Tuning {
+  const char *debug_dump_dir;      // MLT_DEBUG_DUMP_DIR: after every kernel, synchronise and write its output tensor there (bring-up only)
+  int xl_kill, xl_kill_layer;      // MLT_XL_KILL / MLT_XL_KILL_LAYER: exact-lite bring-up, silence a K block (of one layer: cin * 1000 + cout)
+  long lat_pixels;                 // MLT_LAT_PIXELS: launches of at most this many output pixels take the latency variants / per-conv forms (16384; 0 disables)
+  bool no_exact_lat;               // MLT_NO_EXACT_LAT
+  bool exact_patch_big;            // (MLT_EXACT_PATCH_64K clears it) the exact arithmetic's patch planes may use what the weight ring leaves of the LDS
+  int wg_cap, wg_cap0, wg_cap1, wg_cap2;   // MLT_WG_CAP / _CAP0 / _CAP1 / _CAP2: persistent workgroups per launch (256 = one per CU)
+  bool l0_mfma32, l1_mfma32;       // MLT_L0_MFMA32: layer0_stream_kernel on round 5's 32x32x16 MFMAs; layer1_stream_kernel runs them unless MLT_L1_MFMA16 (same bits either way)
+  bool no_chain, no_chain_s2, no_c16, chain64, no_block_fusion, no_l0_s5;   // MLT_NO_CHAIN, _CHAIN_S2, _C16, _CHAIN64, _BLOCK_FUSION, _L0_S5: knock-outs of the fused forms
+  int l0_stream_min, l1_stream_min;        // MLT_L0_STREAM_MIN / MLT_L1_STREAM_MIN (128; MLT_NO_L0_STREAM / MLT_NO_L1_STREAM: 0 = never)
+  int guard_wait_mode;             // 0 sleep-then-poll, 1 MLT_GUARD_SPIN_WAIT, 2 MLT_GUARD_BLOCKING_WAIT
+  bool no_small_mix, no_mag_guard, no_graph;   // MLT_NO_SMALL_MIX, MLT_NO_MAG_GUARD, MLT_NO_GRAPH (also set by MLT_DEBUG_DUMP_DIR)
+};
+const Tuning &tuning() {
+  static const Tuning t = [] {
+    auto num = [](const char *name, long dflt) { const char *e = tuning_env(name); return e ? std::atol(e) : dflt; };
+    auto on = [](const char *name) { return tuning_env(name) != nullptr; };
+    auto cap = [&](const char *name) { const long v = num(name, 0); return (int)(v > 0 ? v : 256); };
+    Tuning u{};
+    u.debug_dump_dir = tuning_env("MLT_DEBUG_DUMP_DIR");
+    u.xl_kill = (int)num("MLT_XL_KILL", 0); u.xl_kill_layer = (int)num("MLT_XL_KILL_LAYER", -1);
+    u.lat_pixels = num("MLT_LAT_PIXELS", 16384L);
+    u.no_exact_lat = on("MLT_NO_EXACT_LAT"); u.exact_patch_big = !on("MLT_EXACT_PATCH_64K");
+    u.wg_cap = cap("MLT_WG_CAP"); u.wg_cap0 = cap("MLT_WG_CAP0"); u.wg_cap1 = cap("MLT_WG_CAP1"); u.wg_cap2 = cap("MLT_WG_CAP2");
+    u.l0_mfma32 = on("MLT_L0_MFMA32"); u.l1_mfma32 = !on("MLT_L1_MFMA16");
+    u.no_block_fusion = on("MLT_NO_BLOCK_FUSION");
+    u.no_chain = on("MLT_NO_CHAIN") || u.no_block_fusion; u.no_chain_s2 = on("MLT_NO_CHAIN_S2"); u.no_c16 = on("MLT_NO_C16"); u.chain64 = !on("MLT_NO_CHAIN64");
+    u.no_l0_s5 = on("MLT_NO_L0_S5");
+    u.l0_stream_min = on("MLT_NO_L0_STREAM") ? 0 : (int)num("MLT_L0_STREAM_MIN", 128);
+    u.l1_stream_min = on("MLT_NO_L1_STREAM") ? 0 : (int)num("MLT_L1_STREAM_MIN", 128);
+    u.guard_wait_mode = on("MLT_GUARD_SPIN_WAIT") ? 1 : on("MLT_GUARD_BLOCKING_WAIT") ? 2 : 0;
+    u.no_small_mix = on("MLT_NO_SMALL_MIX"); u.no_mag_guard = on("MLT_NO_MAG_GUARD");
+    u.no_graph = on("MLT_NO_GRAPH") || u.debug_dump_dir != nullptr;
+    return u;
+  }();
+  return t;
+}
+
 int size_index(int size) {
   switch (size) {
     case 128: return 0;
@@ -292,7 +332,7 @@ void release_ws(mlt_ctx *ctx) {  // (the caller has synchronised the stream)
 // MLT_DEBUG_DUMP_DIR=<dir>: after every kernel, synchronise and write the output tensor to <dir>/<seq>_<name>.bin
 // (bring-up aid only; never set in production or in timed runs).
 int debug_dump(mlt_ctx *ctx, const char *name, const void *dptr, size_t bytes) {
-  static const char *dir = tuning_env("MLT_DEBUG_DUMP_DIR");
+  const char *dir = tuning().debug_dump_dir;
   static int seq = 0;
   if (!dir) return MLT_OK;
   std::vector<char> host(bytes);
@@ -347,18 +387,17 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.x_lo_off = io.x_lo; a.y_lo_off = io.y_lo; a.res_lo_off = io.res_lo; a.ysc_lo_off = io.ysc_lo; a.w_lo_off = pc.plane_halves * 2;
   a.lo8_scale = 0x01010101 * ((127 - pc.lo8_exp) & 0xFF);
   a.xl_sa0 = 0x01010101 * ((127 - pc.xl_ewl) & 0xFF); a.xl_sa1 = 0x01010101 * ((127 - pc.xl_ewh) & 0xFF); a.xl_sb1 = 0x01010101 * (127 - 12);  // (12 = MLT_XL_LO_EXP, mlt_kernels.hip)
-  { static const int kill = [] { const char *e = tuning_env("MLT_XL_KILL"); return e ? std::atoi(e) : 0; }();  // bring-up: E8M0 byte 0 = 2^-127 silences a K block
-    static const int only = [] { const char *e = tuning_env("MLT_XL_KILL_LAYER"); return e ? std::atoi(e) : -1; }();  // cin * 1000 + cout
+  { const int kill = tuning().xl_kill, only = tuning().xl_kill_layer;  // bring-up: E8M0 byte 0 = 2^-127 silences a K block (of one layer: cin * 1000 + cout)
     if (only < 0 || only == pc.cin * 1000 + pc.cout) { if (kill & 1) a.xl_sa0 = 0; if (kill & 2) a.xl_sb1 = 0; } }
   // LDS-DMA staging variants (fast arithmetic): resident weights on maps >= 16 x 16, weight ring on maps >= 8 x 8
   // Small batches (the encoder's one-CU-per-call use): the throughput tiling would put a whole layer on 1-4 workgroups
   // that stream all its weights through their LDS one after the other.  The latency variants cut the couts into 32-channel
   // tiles (4x more workgroups, 4x fewer weight bytes each) on the same packed weights.
-  static const long lat_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
+  const long lat_px = tuning().lat_pixels;  // output pixels of the launch; measured crossover 13-33 k per layer; 0 disables
   // hi+lo weights on the fast tiling (MLT_MODEL_W2): its stride-1 layers with >= 64 channels have ONE per-conv form, the 32-cout x 128-pixel
   // variant (large launches of those layers go through chain_kernel<..., W2>; this is the bit-identical small-launch / fallback form)
   // (its stride-2 layers share their tiling with the exact packing and run that tier's kernels at any launch size)
-  static const bool no_exact_lat = tuning_env("MLT_NO_EXACT_LAT") != nullptr;
+  const bool no_exact_lat = tuning().no_exact_lat;
   const bool lat = !(pc.exact && no_exact_lat) && pc.lat && hout >= 8 && (pc.w2 ? pc.stride == 1 : (long)n * hout * hout <= lat_px);
   const int dma = (pc.exact || pc.w2 || lat) ? 0 : (pc.dma == 1 && hout >= 16) ? 1 : (pc.dma == 2 && hout >= 8) ? 2 : 0;
   const int MT = lat ? 128 : dma == 2 ? pc.mt_dma : pc.mt;
@@ -382,7 +421,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   if (nsplit == 2 || nsplit == 6) {
     const int tt = pc.taps + (pc.has_sc ? 1 : 0), nbuf = tt / pc.gt > 1 ? 2 : 1;
     const size_t ring = (size_t)nbuf * 2 * pc.gt * (pc.kc / 16) * (pc.ct / 32) * 1024;
-    static const bool big = tuning_env("MLT_EXACT_PATCH_64K") == nullptr;
+    const bool big = tuning().exact_patch_big;
     if (big && ring + 64 * 1024 < 160 * 1024) patch_budget = 160 * 1024 - ring;
   }
   while (spw > 1 && (((size_t)spw * ph * rp * PS + 1023) / 1024 * 1024) * act_planes > patch_budget) spw /= 2;
@@ -401,7 +440,7 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
   a.gap = io.gap; a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
   a.ntiles = ((n + spw - 1) / spw) * (hout / th) * (hout / tw);
   // persistent workgroups: at most MLT_WG_PER_CU (default 2) x 256 CUs per cout tile, each looping over tiles
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int wg_cap = tuning().wg_cap;
   // only the weights-resident kernels (single weight step, single channel chunk) are persistent (mlt_kernels.hip PERSIST)
   const int gt = (nsplit == 4 && !lat) ? pc.gt_w2 : pc.gt;  // the hi+lo-weights tier has its own taps-per-step (mlt_conv_cfg)
   const bool persistent = (gt == pc.taps + (pc.has_sc ? 1 : 0) && pc.cin == pc.kc) || dma == 2;
@@ -473,7 +512,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   a.w_lo_off = m.stem_b.plane_halves * 2; a.w2_lo_off = c2.plane_halves * 2; a.scale2 = c2.acc_scale;
   if (d_flat && !flat_is_clear) LAUNCH_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));  // (flat_is_clear: the consumer of the previous call left it zero)
   a.acc_scale = m.stem.acc_scale; a.n = n; a.hout_l = ilog2(h); a.ntiles = n * (h / 16) * (h / 32);
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP2"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();  // one (pipelined) workgroup per CU
+  const int wg_cap = tuning().wg_cap2;  // one (pipelined) workgroup per CU
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "stem+block_s2_2to32_h%d(layer0.0)", h);
@@ -500,7 +539,7 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
   a.y = y; a.flat = d_flat; a.acc_scale = m0.stem.acc_scale; a.n = n;
   if (c5) { a.w5 = c5->d_w; a.bias5 = c5->d_bias; a.bias5_sc = c5->d_bias_sc; a.scale5 = c5->acc_scale; a.y_t = y_t; a.y_sc = y_sc; }
   if (d_flat && !flat_is_clear) LAUNCH_TRY(ctx, hipMemsetAsync(d_flat, 0, (size_t)n * 4, ctx->stream));
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP0"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int wg_cap = tuning().wg_cap0;
   const int grid_x = n > wg_cap ? wg_cap : n;
   const double px = (double)n * 64 * 64;
   Launch L{ctx};
@@ -509,7 +548,7 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
                              (double)n * 128 * 128 * 4 + (px / 4) * 64 * 2 * 2, e0, e1)
               : L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
-  static const bool mfma32 = tuning_env("MLT_L0_MFMA32") != nullptr;   // round 5's MFMA shape (A/B; the results are the same bits)
+  const bool mfma32 = tuning().l0_mfma32;   // round 5's MFMA shape (A/B; the results are the same bits)
   LAUNCH_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (c5) {
@@ -526,7 +565,7 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   a.x = x; a.y = y; a.w1 = B.conv1.d_w; a.w2 = B.conv2.d_w; a.bias1 = B.conv1.d_bias; a.bias2 = B.conv2.d_bias;
   a.w1_lo_off = B.conv1.plane_halves * 2; a.w2_lo_off = B.conv2.plane_halves * 2; a.scale1 = B.conv1.acc_scale; a.scale2 = B.conv2.acc_scale;
   a.n = n; a.h_l = ilog2(h); a.ntiles = n * (h / (w2 ? 8 : 16)) * (h / 32);
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int wg_cap = tuning().wg_cap;
   const int grid_x = a.ntiles > wg_cap ? wg_cap : a.ntiles;
   char name[48];
   std::snprintf(name, sizeof name, "block_s1_32_h%d(conv1+conv2)", h);
@@ -567,7 +606,7 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
   }
   const int hw = h * h;
   a.gap_slots = gap_slots(hw); a.gap_l = hw >= 32 ? 5 : ilog2(hw);
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int wg_cap = tuning().wg_cap;
   const int spw = c == 256 ? 2 : 1;            // samples per workgroup (64 KiB of activations)
   const int ntiles = (n + spw - 1) / spw;
   const int grid_x = ntiles > wg_cap ? wg_cap : ntiles;  // one workgroup per CU (its LDS is full), persistent over tiles
@@ -597,7 +636,7 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
   a.t = t; a.sc = sc; a.y = y; a.y_c16 = y_c16 ? 1 : 0; a.gap = gap; a.gap_slots = gap_slots(32 * 32); a.n = n;
   const mlt::PackedConv *pcs[3] = {&B0.conv2, &B1.conv1, &B1.conv2};
   for (int k = 0; k < 3; ++k) { a.w[k] = pcs[k]->d_w; a.bias[k] = pcs[k]->d_bias; a.scale[k] = pcs[k]->acc_scale; }
-  static const int wg_cap = [] { const char *e = tuning_env("MLT_WG_CAP1"); int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int wg_cap = tuning().wg_cap1;
   const int grid_x = n > wg_cap ? wg_cap : n;
   const double px = (double)n * 32 * 32;
   Launch L{ctx};
@@ -607,7 +646,7 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
   // round 6: the 16x16x32 MFMA form exists (same bits) but measures 2 % SLOWER here than round 5's 32x32x16 form (0.882 against 0.863 ms, same box, alternating:
   // profiles/r06e_mfma16_ab.txt) -- the bare loop's +11 % is a clock effect at 1.6 GHz, this kernel already holds ~2.1 GHz and pays for twice the MFMA issue
   // slots and 8-byte epilogue accesses: it stays on 32x32x16 (MLT_TUNING=1 MLT_L1_MFMA16=1 selects the other form)
-  static const bool mfma32 = tuning_env("MLT_L1_MFMA16") == nullptr;
+  const bool mfma32 = tuning().l1_mfma32;
   LAUNCH_TRY(ctx, mlt_launch_layer1_stream(a, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, "chain3_s1_64_h32(conv2+conv1+conv2)", y, (size_t)px * 64 * 2);
@@ -653,10 +692,9 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   // Which stages run as chain / whole-stage launches (fast arithmetic, large launches; small ones keep the per-conv latency
   // variants: a chain runs its convs one after the other on n workgroups).  Asked for stage s AND for stage s + 1: a stage
   // whose successor is a whole-stage kernel writes its output chunk-major (ConvArgs.y_c16).
-  static const bool no_chain = tuning_env("MLT_NO_CHAIN") != nullptr || tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
-  static const bool no_chain_s2 = tuning_env("MLT_NO_CHAIN_S2") != nullptr;
-  static const bool no_c16 = tuning_env("MLT_NO_C16") != nullptr;
-  static const long chain_min_px = [] { const char *e = tuning_env("MLT_LAT_PIXELS"); return e ? std::atol(e) : 16384L; }();
+  const Tuning &tn = tuning();
+  const bool no_chain = tn.no_chain, no_chain_s2 = tn.no_chain_s2, no_c16 = tn.no_c16;
+  const long chain_min_px = tn.lat_pixels;
   auto model_of = [&](int s, int u) -> mlt::Model & { return ((x_units >> (2 * s + u)) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : m; };
   auto wants_chain = [&](int s, int h_in) -> bool {
     if (s <= 0 || s >= m.n_stages || no_chain) return false;
@@ -666,7 +704,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
     // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
     // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
-    static const bool chain64 = tuning_env("MLT_NO_CHAIN64") == nullptr;
+    const bool chain64 = tn.chain64;
     const bool packing_ok = (m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3)) && (!mm.w2 || c2.lo8 || m.planes[s] == 64);  // what chain_kernel<C> streams
     return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
   };
@@ -697,7 +735,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     ConvIO io;
     io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
     io.x_lo = in_has_lo ? lo_in : 0; io.y_lo = lo_st; io.ysc_lo = lo_st;
-    static const bool no_fuse0 = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
+    const bool no_fuse0 = tn.no_block_fusion;
     // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
     const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
     const bool fused_b0 = s == 0 && !ms.exact && ho >= 32 && !no_fuse0 && quad_ok;
@@ -713,11 +751,11 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups).
     // Round 6: from 128 CUs on -- the measured crossover (one CU per workgroup on half the chip already beats the tiled launches: docs/KERNEL_NOTES.md,
     // "Where the streaming launches start to pay": 128 CUs +3 %, 192 CUs +12 %); round 5 had kept 256
-    static const int l0_min = [] { const char *e = tuning_env("MLT_L0_STREAM_MIN"); return tuning_env("MLT_NO_L0_STREAM") ? 0 : e ? std::atoi(e) : 128; }();
+    const int l0_min = tn.l0_stream_min;
     if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && l0_min > 0 && n >= l0_min) {
       // ... and with it the stride-2 conv + shortcut that open layer1, when the 64-channel chain follows (it wants sc chunk-major) and layer1's first
       // unit runs the single pass too: layer0's output then never reaches HBM
-      static const bool no_f5 = tuning_env("MLT_NO_L0_S5") != nullptr;
+      const bool no_f5 = tn.no_l0_s5;
       const mlt::Model &m10 = model_of(1, 0);
       const mlt::PackedConv &c5 = m10.blocks[1][0].conv1;
       l0_did_s2 = !no_f5 && m.n_stages > 1 && !m10.exact && !m10.w2 && wants_chain(1, 64) && !wants_s2(1, 64) && m.planes[1] == 64 && !no_c16 &&
@@ -751,7 +789,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
       if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
         const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
         // round 5: large batches run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain); round 6: from 128 CUs on
-        static const int l1_min = [] { const char *e = tuning_env("MLT_L1_STREAM_MIN"); return tuning_env("MLT_NO_L1_STREAM") ? 0 : e ? std::atoi(e) : 128; }();
+        const int l1_min = tn.l1_stream_min;
         const mlt::PackedConv &q2 = B0c.conv2;
         if (s == 1 && !chain_s2 && m.planes[s] == 64 && hout == 32 && io.ysc_c16 && !mt.w2 && !mt.exact && l1_min > 0 && n >= l1_min &&
             q2.taps == 9 && q2.kc == 64 && q2.ct == 64 && outs[s] && !last) {
@@ -775,7 +813,7 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
     // block 1 (identity shortcut)
     mlt::Block &B1 = mt.blocks[s][1];
-    static const bool no_fuse = tuning_env("MLT_NO_BLOCK_FUSION") != nullptr;
+    const bool no_fuse = tn.no_block_fusion;
     if (s == 0 && !mt.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
       if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
       cur = outs[s];
@@ -956,7 +994,7 @@ int run_checked(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, const int3
   // 5 ms batch -- in the encoder host cores are the scarce resource -- and the caller's next batch is still enqueued the moment this one
   // is through (a plain blocking wait wakes up on an interrupt and left the GPU idle for ~0.14 ms per 4096-CU step, 2.8 %).
   // MLT_GUARD_SPIN_WAIT=1: poll from the start (one busy core); MLT_GUARD_BLOCKING_WAIT=1: hipEventSynchronize on a blocking-sync event.
-  static const int wait_mode = tuning_env("MLT_GUARD_SPIN_WAIT") ? 1 : tuning_env("MLT_GUARD_BLOCKING_WAIT") ? 2 : 0;
+  const int wait_mode = tuning().guard_wait_mode;
   if (!ctx->ev_guard) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_guard, hipEventDisableTiming | hipEventBlockingSync));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_guard, ctx->stream));
   if (wait_mode == 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_guard));
@@ -1515,7 +1553,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MLT_ERR_NO_DEVICE; }
   std::string err;
   mlt::Model m;
-  static const bool no_small_mix = tuning_env("MLT_NO_SMALL_MIX") != nullptr;
+  const bool no_small_mix = tuning().no_small_mix;
   const bool small_mix = st.small_mix && !no_small_mix;   // (then: fast copy = `model`, exact copy = `model_exact`, the calibration picks the stages)
   if (!mlt::build_model(blob, bytes, (st.want_exact && !small_mix) ? (ctx->xlite ? mlt::MLT_MODEL_XLITE : mlt::MLT_MODEL_EXACT) : mlt::MLT_MODEL_FAST, size, m, err)) { ctx->err = "weights: " + err; return MLT_ERR_WEIGHTS; }
   if (m.arch != (size == 128 ? 0 : 1)) { ctx->err = "weights: blob arch does not match CU size"; return MLT_ERR_WEIGHTS; }
@@ -1558,7 +1596,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
       //       profiles/r04s_tail_probe_{64,32}.txt measured 1.5 .. 1.85 x the calibration set's largest error).
       CalibSession cal(ctx, st, extra);
       // (the magnitude guard serves the 128 model's tiers; the small models' search is over exact prefixes and is left as it was)
-      static const bool no_mag = tuning_env("MLT_NO_MAG_GUARD") != nullptr;
+      const bool no_mag = tuning().no_mag_guard;
       cal.want_mag = !small_mix && st.cfg_mag_guard && !no_mag;
       if ((rc = cal.begin())) return fail(rc);
       DevicePricer pricer(ctx, st, cal, blob, bytes, size);
@@ -2177,7 +2215,7 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
     int r = run_guarded_async(ctx, *st, 1, pl, d_sc, d_sc + 1, d_sc + 2, (float *)(d_sc + 4), g);  // its 4-byte count D2H lands in h_sc[3]
     return r;
   };
-  static const bool no_graph = tuning_env("MLT_NO_GRAPH") != nullptr || tuning_env("MLT_DEBUG_DUMP_DIR") != nullptr;
+  const bool no_graph = tuning().no_graph;
   bool replayed = false;
   if (!no_graph && !ctx->profile && ctx->own_stream) {
     if (sg.exec && (sg.ws_gen_at_capture != ctx->ws_gen || sg.stream_at_capture != ctx->stream)) {  // workspace re-allocated since: re-capture
