@@ -39,6 +39,8 @@ for f in sorted(glob.glob(os.path.join(run, "bench_*.json"))):  # round 4: the o
 if os.path.exists(os.path.join(run, "lat", "out_kernel_trace.csv")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "latency_timeline.py"), os.path.join(run, "lat", "out_kernel_trace.csv"),
                            os.path.join(prof, f"{tag}_single_cu_timeline.csv")])
+if os.path.exists(os.path.join(run, "flush_latency.txt")):
+    open(os.path.join(prof, f"{tag}_flush_latency.txt"), "w").write("".join(l for l in open(os.path.join(run, "flush_latency.txt")) if "amdgpu.ids" not in l))
 if os.path.exists(os.path.join(run, "latency_modes.txt")):
     open(os.path.join(prof, f"{tag}_latency_modes.txt"), "w").write("".join(l for l in open(os.path.join(run, "latency_modes.txt")) if "amdgpu.ids" not in l))
 sig = json.load(open(os.path.join(run, "bench_line.json")))["derived"]["source_sig"]  # sources the evidence run was built from

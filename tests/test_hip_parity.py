@@ -1195,6 +1195,15 @@ def test_magnitude_guard(gpu):
         assert s1 == s[i] and np.array_equal(l1, l[i]), ("deferred", i)
     s2, l2 = m.predict_batch(org[nt - 8:nt + nn + 8], pred[nt - 8:nt + nn + 8], poc[nt - 8:nt + nn + 8], qp[nt - 8:nt + nn + 8])
     assert np.array_equal(l2, l[nt - 8:nt + nn + 8]) and np.array_equal(s2, s[nt - 8:nt + nn + 8])
+    # an ABI-4 caller's 72-byte mlt_arith_info (before the two magnitude-guard floats) is still accepted and nothing is written behind it
+    import ctypes as C
+    raw = (C.c_ubyte * 96)(*([0xAB] * 96))
+    C.cast(raw, C.POINTER(C.c_uint32))[0] = 72
+    lib = pkg.capi.load_library()
+    assert lib.mlt_arithmetic(m._h, size, C.cast(raw, C.POINTER(pkg.capi.MltArithInfo))) == 0
+    assert all(b == 0xAB for b in raw[72:]) and C.cast(raw, C.POINTER(C.c_int32))[1] == a["exact"]
+    C.cast(raw, C.POINTER(C.c_uint32))[0] = 64
+    assert lib.mlt_arithmetic(m._h, size, C.cast(raw, C.POINTER(pkg.capi.MltArithInfo))) == 1     # MLT_ERR_ARG: does not cover the ABI-4 fields
     # the seeded bench set is admitted by the plain rule: no magnitude guard, nothing changes for it
     b10 = _ctx(pkg, size, pkg.weights.synthetic_blob(0, 10))
     a10 = b10.arithmetic(size)
