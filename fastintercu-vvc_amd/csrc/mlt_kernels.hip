@@ -796,10 +796,13 @@ template <bool F5, bool M16> static hipError_t launch_layer0_stream_t(const Laye
   hipLaunchKernelGGL((layer0_stream_kernel<F5, M16>), dim3(grid_x), dim3(1024), F5 ? MLT_L0F_LDS_BYTES : MLT_L0_LDS_BYTES, st, a);  // one persistent workgroup per CU slot
   return hipGetLastError();
 }
-// fuse5: + layer1's stride-2 conv and shortcut as a fifth stage; mfma32: round 5's MFMA shape (MLT_TUNING=1 MLT_L0_MFMA32=1: same-box A/B; same bits)
+// fuse5: + layer1's stride-2 conv and shortcut as a fifth stage; mfma32: round 5's MFMA shape (MLT_TUNING=1 MLT_L0_MFMA32=1: same-box A/B; same bits).
+// The four-stage form (fuse5 = false: weight sets whose layer1 does not open on the single pass) stays on 32x32x16: its 16x16x32 build reloads three of S2's
+// weight fragments from scratch every row (S2 carries two accumulator sets; the five-stage form's register allocation comes out without that), and it
+// was the five-stage form the A/B measured.
 hipError_t mlt_launch_layer0_stream(const Layer0Args &a, bool fuse5, bool mfma32, int grid_x, hipStream_t st) {
   if (fuse5) return mfma32 ? launch_layer0_stream_t<true, false>(a, grid_x, st) : launch_layer0_stream_t<true, true>(a, grid_x, st);
-  return mfma32 ? launch_layer0_stream_t<false, false>(a, grid_x, st) : launch_layer0_stream_t<false, true>(a, grid_x, st);
+  return launch_layer0_stream_t<false, false>(a, grid_x, st);
 }
 
 hipError_t mlt_launch_layer1_stream(const Layer1Args &a, bool mfma32, int grid_x, hipStream_t st) {

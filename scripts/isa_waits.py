@@ -53,6 +53,30 @@ def collect(defs):
     return stats
 
 
+def scratch_in_loops(prefix, path="/tmp/isa_waits.s"):
+    """[(asm line, depth, text)] of the scratch_* instructions of the kernels whose demangled name starts with `prefix` that sit inside a loop (collect() wrote `path`)"""
+    hits, name, depth = [], None, 0
+    for ln, line in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name = re.sub(r"^void ", "", subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip())
+            depth = 0
+            continue
+        if name is None or not name.startswith(prefix):
+            continue
+        if "s_endpgm" in line:
+            name = None
+            continue
+        m = re.search(r"Depth[= ](\d+)", line)
+        if m and line.lstrip().startswith((".LBB", ";")):
+            depth = int(m.group(1))
+        elif line.startswith(".LBB") and "Loop" not in line:
+            depth = 0
+        if line.strip().startswith("scratch_") and depth >= 1:
+            hits.append((ln, depth, line.strip()))
+    return hits
+
+
 def main():
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
     want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else ""
