@@ -136,6 +136,29 @@ def main():
     rows.append({"impl": "torch-CPU port (oracle/torch_port.py, oneDNN fp32)", "batch": f"{n} (sample of the 4096-CU batch, {args.per_proc} per process)",
                  "procs": P, "threads": T, "value": round(n / med, 2), "median_s": round(med, 5), "runs": args.runs, "warmup": args.warmup})
     best = max(rows, key=lambda r: r["value"])
+    # ---- optional second row of BASELINE.md section 3: the reference's CALL PATTERN -- the model file is re-read and re-materialised on every
+    # call (EncCu.cpp:894-900: torch::jit::load + .eval() per CU) -- one CU per call, best thread count of the batch-1 sweep.  Here: the MLTW
+    # blob re-read from a file and its tensors rebuilt per call (no TorchScript graph to parse: a LOWER bound of what the reference pays).
+    # Reported, never the headline denominator (`value` above is chosen before this row exists).
+    try:
+        import tempfile
+        T1 = rows[0]["threads"]
+        torch.set_num_threads(T1)
+        with tempfile.NamedTemporaryFile(suffix=".mltw") as tf:
+            tf.write(blob)
+            tf.flush()
+            ts = []
+            for i in range(2 + 8):
+                t0 = time.perf_counter()
+                with open(tf.name, "rb") as fh:
+                    TorchPort(fh.read()).forward(org[:1], pred[:1], poc[:1], qp[:1], chunk=64)
+                if i >= 2:
+                    ts.append(time.perf_counter() - t0)
+        med1 = statistics.median(ts)
+        rows.append({"impl": "torch-CPU port, weights re-read and rebuilt on EVERY call (the reference's call pattern, EncCu.cpp:894-900; not a candidate for `value`)",
+                     "batch": 1, "procs": 1, "threads": T1, "value": round(1.0 / med1, 2), "median_s": round(med1, 5), "runs": len(ts), "warmup": 2})
+    except Exception as e:  # the optional row must never cost the baseline
+        rows.append({"impl": "reload-per-call row failed", "error": str(e)[:200], "value": 0.0, "batch": 1, "procs": 1, "threads": 0})
     out = {"value": best["value"], "unit": "CU-inferences/s", "cores": best["procs"] * best["threads"], "kind": "port",
            "sample": f"{best['batch']} CUs per run, {best['procs']} processes x {best['threads']} threads, median of {args.runs} after {args.warmup} warm-ups",
            "cpu_model": model, "physical_cores": physical, "logical_cpus": logical, "rows": rows}

@@ -75,11 +75,12 @@ if "--markdown" in sys.argv:
             if row and roof_kernel in row[0]:
                 batch_ms = float(row[3]) / 1e6
     lat = {l.split()[1]: float(l.split()[4]) for l in open(os.path.join(P, f"{tag}_latency_modes.txt")) if l.startswith("tier")}
-    seeds = {n: b(f"seed{n}") for n in (11, 12, 13, 21, 22, 23, 24)}
+    seeds = {n: b(f"seed{n}") for n in (11, 12, 13, 21, 22, 23, 24, 25) if os.path.exists(os.path.join(P, f"{tag}_bench_seed{n}.json"))}
     sz = {n: b(f"s{n}") for n in (64, 32, 16)}
     nat, flat, ex = b("natural"), b("flat25"), b("exact")
     dg = b("no_decision_guard") if os.path.exists(os.path.join(P, f"{tag}_bench_no_decision_guard.json")) else b("decision_guard")  # (round 5: the guard is the default; the extra leg is the run WITHOUT it)
-    rows_cpu = {str(x.get("batch"))[:4]: x["value"] for x in cb["rows"]}
+    rows_cpu = {str(x.get("batch"))[:4]: x["value"] for x in cb["rows"] if "EVERY call" not in x.get("impl", "")}
+    reload_row = next((x["value"] for x in cb["rows"] if "EVERY call" in x.get("impl", "")), None)
     print(f"| **CU-inferences/s, batch 4096 x 128x128**, seed 10 | **{d['value'] / 1e3:.0f} k** ({d['ms_per_step']:.2f} ms per batch); {dv['model_tflops']:.0f} TFLOP/s over the whole net = {dv['mfma_frac_whole_net']:.2f} of 2.5 PFLOP/s |")
     print(f"| parity over the whole timed batch | max |dlogit| {d['parity']['max_abs_dlogit']:.1e}; {d['parity']['split_mismatch_decisive']} split mismatches; {d['parity']['non_decisive']} CUs below the decidable margin |")
     print(f"| roofline kernel {r['kernel']} | {r['avg_launch_ms']:.3f} ms (HIP events; rocprofv3 batch launches {batch_ms:.3f} ms) = {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f}; SQ_VALU_MFMA_BUSY {100 * float(sq.get('mfma_util', 0)):.1f} %, bank conflicts {100 * float(sq.get('lds_conflict_frac', 0)):.1f} %; PMC traffic {next(v['hbm_bytes_per_launch'] for n, v in json.load(open(os.path.join(P, f'{tag}_pmc_traffic.json'))).items() if n.startswith(r['kernel'].split('(')[0])) / 1e9:.2f} GB vs {r['algo_bytes_per_launch'] / 1e9:.2f} GB |")
@@ -88,8 +89,8 @@ if "--markdown" in sys.argv:
     print(f"| other launches | {front} . 64-channel stage {ms('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.3f} ({rf('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.2f}) . layer3 {ms('stage_256'):.3f} ({rf('stage_256'):.2f}) . heads {ms('heads'):.3f} . guard select {ms('guard_select'):.3f} |")
     print(f"| whole path | {dv['whole_path']['t_bound_ms']:.3f} / {dv['whole_path']['t_measured_ms']:.3f} = {dv['whole_path']['frac']:.2f}; HBM layer-wise fraction {dv['hbm_layerwise_roofline_frac']:.2f} |")
     print(f"| decision guard | {dg['value'] / 1e3:.0f} k |")
-    print("| other weight sets | " + " . ".join(f"{n}: {seeds[n]['value'] / 1e3:.0f} k ({seeds[n]['parity']['max_abs_dlogit']:.1e})" for n in (23, 11, 13, 24, 21, 22, 12)) + f" . exact: {ex['value'] / 1e3:.0f} k |")
+    print("| other weight sets | " + " . ".join(f"{n}: {seeds[n]['value'] / 1e3:.0f} k ({seeds[n]['parity']['max_abs_dlogit']:.1e})" for n in (23, 24, 13, 11, 21, 25, 12, 22) if n in seeds) + f" . exact: {ex['value'] / 1e3:.0f} k |")
     print(f"| content | natural {nat['value'] / 1e3:.0f} k ({nat['config']['arithmetic']['guard_rerun_fraction'] * 100:.2f} % flagged, {nat['parity']['max_abs_dlogit']:.1e}) . 25 % flat {flat['value'] / 1e3:.0f} k |")
-    print(f"| CPU baseline | {cb['value']:.0f} CU/s; one CU at a time {rows_cpu.get('1', 0):.0f}; C oracle {rows_cpu.get('None', 0):.0f} |")
+    print(f"| CPU baseline | {cb['value']:.0f} CU/s; one CU at a time {rows_cpu.get('1', 0):.0f}; C oracle {rows_cpu.get('None', 0):.0f}" + (f"; weights re-read on every call (the reference's call pattern) {reload_row:.0f}" if reload_row else "") + " |")
     print(f"| latency / host-staged | {e.get('batch1_sync_call_us'):.0f} us (tier 3: {lat.get('3', 0):.0f}, tier 4: {lat.get('4', 0):.0f}) / {e.get('host_staged_cu_per_s', 0) / 1e3:.0f} k |")
     print("| 64 / 32 / 16 | " + " / ".join(f"{sz[n]['value'] / 1e6:.2f} M" for n in (64, 32, 16)) + "; max |dlogit| " + " / ".join(f"{sz[n]['parity']['max_abs_dlogit']:.1e}" for n in (64, 32, 16)) + "; CPU " + " / ".join(f"{sz[n]['cpu_baseline']['value'] / 1e3:.1f} k" for n in (64, 32, 16)) + " |")
