@@ -441,10 +441,11 @@ def main():
                                "inputs (int16 org+pred, int32 poc/qp) resident in HBM, outputs logits+split in HBM",
                    "batch_per_gpu": B, "cu_size": size, "weights": (f"MLTW file {os.path.basename(args.weights_blob)}" if args.weights_blob else f"synthetic seed {args.weight_seed}") + " (no trained checkpoint is distributed)",
                    "parallelism": f"shard{world}",
-                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else "exact-lite (fp16 hi x hi + both cross terms in one scaled FP8 MFMA: 2 fp16-equivalent passes)" + (" + decision guard" if arith["decision_guard"] else "") if tier == 5 else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else "") + (f" + magnitude guard (logit magnitude > {arith['mag_guard_thr']:.3g} re-run exactly)" if arith["mag_guard_thr"] > 0 else ""),
+                   "arithmetic": {"mode": "exact (fp16 hi+lo pairs, 3 MFMA passes)" if exact else "exact-lite (fp16 hi x hi + both cross terms in one scaled FP8 MFMA: 2 fp16-equivalent passes)" + (" + decision guard" if arith["decision_guard"] else "") if tier == 5 else ("hi+lo weights (2 MFMA passes)" if tier == 2 else f"hi+lo weights in {stages}, single pass in the other stages" if tier == 3 else f"exact in {xstages}, hi+lo weights in {stages or 'no stage'}, single pass in the others" if tier == 4 else "fast (single fp16 pass)") + (" + flat-content guard" if arith["flat_guard"] else "") + (" + decision guard" if arith["decision_guard"] else "") + (f" + magnitude guard (logit magnitude > {arith['mag_guard_thr']:.3g} re-run exactly)" if arith["mag_guard_kind"] == 2 else ""),
                                   "calibrated_at_load": bool(arith["calibrated"]), "calib_rms_dlogit": arith["calib_rms"], "calib_max_dlogit": arith["calib_max"],
                                   "w2_stages": int(arith["w2_stages"]), "w2_units": int(arith["w2_units"]), "x_stages": int(arith["x_stages"]), "x_units": int(arith["x_units"]), "weight_rounding": int(arith["rounding"]), "decision_guard_margin": arith["guard_margin"],
                                   "magnitude_guard_thr": arith["mag_guard_thr"], "magnitude_guard_flagged_at_calibration": arith["mag_guard_flagged"],
+                                  "magnitude_guard_kind": {0: "none", 1: "range (1.5 x the largest calibrated magnitude)", 2: "admission (the tier was admitted behind it)"}[int(arith["mag_guard_kind"])],
                                   "guard_reruns_total": arith["guard_reruns"], "guard_reruns_per_step": round(reruns_per_step, 2),
                                   "guard_rerun_fraction": round(reruns_per_step / B, 5)},
                    "content": args.content if args.flat_frac == 0 else f"{args.content} + {args.flat_frac:g} flat / dither / ramp / low-contrast CUs"},

@@ -41,7 +41,8 @@ class MltArithInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("exact", C.c_int32), ("calibrated", C.c_int32), ("calib_rms", C.c_float), ("calib_max", C.c_float),
                 ("flat_guard", C.c_int32), ("decision_guard", C.c_int32), ("guard_reruns", C.c_uint64),
                 ("w2_stages", C.c_int32), ("guard_margin", C.c_float), ("x_stages", C.c_int32), ("w2_units", C.c_int32), ("x_units", C.c_int32), ("rounding", C.c_int32),
-                ("calib_cus", C.c_int32), ("calib_caller_cus", C.c_int32), ("mag_guard_thr", C.c_float), ("mag_guard_flagged", C.c_float)]
+                ("calib_cus", C.c_int32), ("calib_caller_cus", C.c_int32), ("mag_guard_thr", C.c_float), ("mag_guard_flagged", C.c_float),
+                ("mag_guard_kind", C.c_int32)]
 
 
 class MltKernelTime(C.Structure):

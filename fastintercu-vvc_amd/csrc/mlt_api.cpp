@@ -127,6 +127,12 @@ struct SizeState {
   // measured at load time (calib_rel, over EVERY calibration CU) reaches max_frac x tolerance.  0: off (every seeded weight set: their
   // error does not follow M, they are admitted -- or not -- by the plain rule as before).
   float mag_thr = 0.f, calib_rel = 0.f, mag_flag = 0.f;
+  int mag_kind = 0;            // 0: no magnitude guard; 2: the tier was ADMITTED behind it (threshold from the admission rule, above); 1: RANGE guard -- a tier the plain rule
+                               // admitted is still only validated on the magnitudes its calibration CUs had, and its error grows linearly with M: CUs beyond
+                               // kMagRange x the largest calibrated magnitude are re-evaluated exactly (1.5 x the 0.65-of-tolerance the largest calibration error
+                               // may reach = the tolerance).  Costs nothing on content inside the calibrated range; it is what stands between a tier and
+                               // content it has never been priced on (scripts/r06_lite_range_probe.py: the exact-lite arithmetic forced onto activations
+                               // beyond its e4m3 range is off by 2e-2)
   bool cfg_mag_guard = true;   // (MLT_FLAG_NO_MAGNITUDE_GUARD clears it)
   float calib_rms = 0.f, calib_max = 0.f;
   int calib_cus = 0, calib_caller_cus = 0;   // CUs the last calibration priced (after dropping those the flat guard re-evaluates anyway) / of them the caller's (mlt_calibrate)
@@ -1111,6 +1117,7 @@ const CalibInputs &calibration_set(int S) {
 // log-uniform 6 ... 160 ten-bit steps around a mean of 120 ... 900, +-1 step of sensor noise; prediction = the scene displaced by a motion vector
 // in [-2, 2]^2, smoothed by [1 2 1]^2 / 16 with probability 1/2, + noise of amplitude 0 ... 6.  Only priced for configurations the plain rule
 // rejects; generated once per process (~0.2 s).
+constexpr float kMagRange = 1.5f;   // range guard: a plain-admitted tier is trusted up to this multiple of the largest logit magnitude of its calibration CUs
 constexpr int kClassScenes = kCalibClasses + 1;   // content class ids: 0 .. 5 synthetic, kCalibClasses = the caller's, kClassScenes = the 1/f scenes
 constexpr int kCalibExtraTexture = 160, kCalibExtraScenes = 160, kCalibExtraN = kCalibExtraTexture + kCalibExtraScenes;
 
@@ -1568,7 +1575,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   st.exact = st.want_exact && !small_mix;
   st.lite = false; st.flat_guard = st.cfg_flat_guard; st.flat_div = 8; st.guard_margin = ctx->guard_margin;
   st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
-  st.mag_thr = 0.f; st.calib_rel = 0.f; st.mag_flag = 0.f;
+  st.mag_thr = 0.f; st.calib_rel = 0.f; st.mag_flag = 0.f; st.mag_kind = 0;
   st.calibrated = false; st.calib_rms = st.calib_max = 0.f;
   st.calib_cus = st.calib_caller_cus = 0;
   st.model = std::move(m);
@@ -1640,8 +1647,15 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
         st.w2_mask = mlt::stages_of_units(ch.w2_units); st.x_mask = mlt::stages_of_units(ch.x_units);
         if (!st.w2) { free_model(st.model_w2); st.model_w2 = mlt::Model(); }
         st.mag_thr = ch.mag_thr; st.mag_flag = ch.mag_flag;   // > 0: the tier was admitted behind the magnitude guard
-        if (st.mag_thr > 0.f) st.flat_div = 16;               // ... and then runs the flat guard at 1 / 16 (CalibSession::price_guarded)
+        if (st.mag_thr > 0.f) { st.flat_div = 16; st.mag_kind = 2; }   // ... and then runs the flat guard at 1 / 16 (CalibSession::price_guarded)
         st.calib_rel = ch.mag_thr > 0.f ? ch.price.max / ch.mag_thr : 0.f;
+      }
+      // the RANGE guard of every non-exact tier the plain rule admitted (SizeState.mag_kind == 1)
+      if (!st.exact && st.mag_kind == 0 && cal.want_mag && cal.main.mag.size() == (size_t)cal.main.n) {
+        float m_hi = 0.f;
+        for (int i = 0; i < cal.main.n; ++i)
+          if (cal.main.use[(size_t)i] && cal.main.mag[(size_t)i] > m_hi) m_hi = cal.main.mag[(size_t)i];
+        if (m_hi > 0.f && std::isfinite(m_hi)) { st.mag_thr = kMagRange * m_hi; st.mag_kind = 1; }
       }
     }
   }
@@ -1661,7 +1675,7 @@ int load_all(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
     if (rc) ctx->err = "device " + std::to_string(p->device) + ": " + p->err;
     else {
       const SizeState &a = ctx->sz[si], &b = p->sz[si];
-      if (a.exact != b.exact || a.lite != b.lite || a.w2 != b.w2 || a.w2_units != b.w2_units || a.x_units != b.x_units || a.model.rounding != b.model.rounding || a.mag_thr != b.mag_thr) {
+      if (a.exact != b.exact || a.lite != b.lite || a.w2 != b.w2 || a.w2_units != b.w2_units || a.x_units != b.x_units || a.model.rounding != b.model.rounding || a.mag_thr != b.mag_thr || a.mag_kind != b.mag_kind) {
         ctx->err = "device " + std::to_string(p->device) + " calibrated to a different arithmetic than device " + std::to_string(ctx->device);
         rc = MLT_ERR_WEIGHTS;
       }
@@ -1827,6 +1841,7 @@ int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out) {
   if (out->struct_size >= sizeof(mlt_arith_info)) {  // round 6 fields: written only into a struct that has them
     out->mag_guard_thr = st->exact ? 0.f : st->mag_thr;
     out->mag_guard_flagged = st->exact ? 0.f : st->mag_flag;
+    out->mag_guard_kind = st->exact ? 0 : st->mag_kind;
   }
   return MLT_OK;
 }

@@ -57,7 +57,7 @@ def gather_results(split: np.ndarray, logits: np.ndarray, total: int, dist, devi
 
 # what identifies the arithmetic a rank's load-time calibration chose (mlt_arith_info): two ranks that differ in any of these would produce
 # different bits for the same CU -- and different throughput -- inside one job
-ARITH_KEYS = ("exact", "w2_stages", "w2_units", "x_stages", "x_units", "rounding", "flat_guard", "decision_guard", "guard_margin", "mag_guard_thr")
+ARITH_KEYS = ("exact", "w2_stages", "w2_units", "x_stages", "x_units", "rounding", "flat_guard", "decision_guard", "guard_margin", "mag_guard_thr", "mag_guard_kind")
 
 
 def agree_on_arithmetic(arith: dict, dist, src: int = 0) -> dict:

@@ -172,8 +172,12 @@ typedef struct mlt_arith_info {
    * 1/f scenes) -- meet the admission rule in its stricter "refinement" form (5.5 .. 6.5 x rms <= 0.95 x, max <= 0.6 x tolerance) with at most
    * 5 % of the in-distribution CUs above it; calib_rms / calib_max are the figures of the CUs at or below it.  0: the tier was admitted by the
    * plain rule, no such guard. */
-  float mag_guard_thr;
+  float mag_guard_thr;      /* the threshold in effect (0: no magnitude guard: exact arithmetic, small models, MLT_FLAG_NO_MAGNITUDE_GUARD) */
   float mag_guard_flagged;  /* fraction of the in-distribution calibration CUs (texture, 1/f scenes, the caller's) above the threshold: what the guard costs on ordinary content */
+  int32_t mag_guard_kind;   /* 2: the tier was admitted BEHIND the guard (above).  1: RANGE guard -- the plain rule admitted the tier, which is still only validated on
+                               the magnitudes its calibration CUs had while its error grows linearly with M: mag_guard_thr = 1.5 x the largest calibrated magnitude
+                               (1.5 x the 0.65 x tolerance its largest calibration error may reach = the tolerance); nothing inside the calibrated range is ever
+                               flagged.  0: none */
 } mlt_arith_info;
 int mlt_arithmetic(mlt_ctx *ctx, int size, mlt_arith_info *out);
 

@@ -35,8 +35,8 @@ def test_config_struct_layout(pkg):
     assert pkg.capi.MltConfig.n_devices.offset == 56 and pkg.capi.MltConfig.devices.offset == 60
     assert pkg.capi.MltConfig.guard_margin.offset == 44
     assert pkg.capi.MltConfig.tolerance.offset == 48
-    assert C.sizeof(pkg.capi.MltArithInfo) == 80   # ABI 4 (72 bytes: struct_size in front of the ABI-3 fields) + round 6's two magnitude-guard floats (the library writes only what fits)
-    assert pkg.capi.MltArithInfo.mag_guard_thr.offset == 72 and pkg.capi.MltArithInfo.mag_guard_flagged.offset == 76
+    assert C.sizeof(pkg.capi.MltArithInfo) == 88   # ABI 4 (72 bytes: struct_size in front of the ABI-3 fields) + round 6's magnitude-guard fields (the library writes only what fits)
+    assert pkg.capi.MltArithInfo.mag_guard_thr.offset == 72 and pkg.capi.MltArithInfo.mag_guard_flagged.offset == 76 and pkg.capi.MltArithInfo.mag_guard_kind.offset == 80
     assert pkg.capi.MltArithInfo.struct_size.offset == 0 and pkg.capi.MltArithInfo.guard_reruns.offset == 32
     assert pkg.capi.MltArithInfo.w2_stages.offset == 40 and pkg.capi.MltArithInfo.guard_margin.offset == 44 and pkg.capi.MltArithInfo.rounding.offset == 60 and pkg.capi.MltArithInfo.calib_caller_cus.offset == 68
     assert pkg.capi.MltConfig.weights_dir.offset == 8

@@ -149,7 +149,7 @@ def test_content_classes_against_oracle(gpu, seed):
             assert report[(k, "default")][1] == n and report[(k, "no decision guard")][1] == n, (k, report[(k, "default")])
         # partial_flat sits just UNDER the flat guard's 1/8 by construction: it stays on the main arithmetic -- unless the tier was admitted behind the
         # magnitude guard (round 6: seed 21), which runs the flat guard at 1/16 and therefore takes every one of these CUs
-        assert report[("partial_flat", "no decision guard")][1] == (n if m.arithmetic(size)["mag_guard_thr"] > 0 else 0)
+        assert report[("partial_flat", "no decision guard")][1] == (n if m.arithmetic(size)["mag_guard_kind"] == 2 else 0)
     for _, c in ctxs:
         c.close()
 
@@ -1153,12 +1153,12 @@ def test_magnitude_guard(gpu):
     m = _ctx(pkg, size, blob)
     a = m.arithmetic(size)
     print("behind the magnitude guard:", a)
-    assert a["calibrated"] == 1 and a["exact"] in (0, 2, 3, 4) and a["mag_guard_thr"] > 0.0, a
+    assert a["calibrated"] == 1 and a["exact"] in (0, 2, 3, 4) and a["mag_guard_thr"] > 0.0 and a["mag_guard_kind"] == 2, a
     assert 0.0 <= a["mag_guard_flagged"] <= 0.05 and 5.5 * a["calib_rms"] <= 1e-3 and a["calib_max"] <= 0.65e-3 and a["calib_cus"] == 560
     plain = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_NO_MAGNITUDE_GUARD)
     ap = plain.arithmetic(size)
     print("plain rule:", ap)
-    assert ap["mag_guard_thr"] == 0.0 and ap["exact"] in (1, 4, 5), ap          # (what round 5 gave this family: exact stages, exact-lite or exact)
+    assert ap["mag_guard_thr"] == 0.0 and ap["mag_guard_kind"] == 0 and ap["exact"] in (1, 4, 5), ap          # (what round 5 gave this family: exact stages, exact-lite or exact)
     # mixed content: texture (ordinary), natural scenes, uniform noise / constant planes (huge residuals)
     nt, nn, nu = 96, 64, 24
     ot, pt = pkg.synth.make_patches_bulk(size, nt, 8101)
@@ -1197,16 +1197,20 @@ def test_magnitude_guard(gpu):
     assert np.array_equal(l2, l[nt - 8:nt + nn + 8]) and np.array_equal(s2, s[nt - 8:nt + nn + 8])
     # an ABI-4 caller's 72-byte mlt_arith_info (before the two magnitude-guard floats) is still accepted and nothing is written behind it
     import ctypes as C
-    raw = (C.c_ubyte * 96)(*([0xAB] * 96))
+    raw = (C.c_ubyte * 104)(*([0xAB] * 104))
     C.cast(raw, C.POINTER(C.c_uint32))[0] = 72
     lib = pkg.capi.load_library()
     assert lib.mlt_arithmetic(m._h, size, C.cast(raw, C.POINTER(pkg.capi.MltArithInfo))) == 0
     assert all(b == 0xAB for b in raw[72:]) and C.cast(raw, C.POINTER(C.c_int32))[1] == a["exact"]
     C.cast(raw, C.POINTER(C.c_uint32))[0] = 64
     assert lib.mlt_arithmetic(m._h, size, C.cast(raw, C.POINTER(pkg.capi.MltArithInfo))) == 1     # MLT_ERR_ARG: does not cover the ABI-4 fields
-    # the seeded bench set is admitted by the plain rule: no magnitude guard, nothing changes for it
+    # the seeded bench set is admitted by the plain rule: it gets the RANGE guard only -- 1.5 x the largest magnitude of its calibration CUs, which
+    # nothing of the calibrated content classes reaches (no re-run on 96 texture + 64 natural + 24 uniform CUs) -- and keeps the flat guard at 1/8
     b10 = _ctx(pkg, size, pkg.weights.synthetic_blob(0, 10))
     a10 = b10.arithmetic(size)
-    assert a10["exact"] == 0 and a10["mag_guard_thr"] == 0.0 and a10["mag_guard_flagged"] == 0.0
+    assert a10["exact"] == 0 and a10["mag_guard_kind"] == 1 and a10["mag_guard_thr"] > 0.0 and a10["mag_guard_flagged"] == 0.0
+    r0 = a10["guard_reruns"]
+    b10.predict_batch(org[:nt + nn + nu], pred[:nt + nn + nu], poc[:nt + nn + nu], qp[:nt + nn + nu])
+    assert b10.arithmetic(size)["guard_reruns"] - r0 <= 6, "the range guard must not touch content inside the calibrated range (a few flat / near-tie CUs aside)"
     for c in (m, plain, ex, b10):
         c.close()

@@ -86,7 +86,7 @@ def _agree_worker(rank, world, port, differ, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     arith = {"exact": 0, "w2_stages": 0, "w2_units": 0, "x_stages": 0, "x_units": 0, "rounding": 0, "flat_guard": 1, "decision_guard": 1,
-             "guard_margin": 3e-3, "mag_guard_thr": 0.0, "calib_rms": 1.6e-4 + 1e-6 * rank, "guard_reruns": rank}   # (figures outside ARITH_KEYS may differ)
+             "guard_margin": 3e-3, "mag_guard_thr": 31.5, "mag_guard_kind": 1, "calib_rms": 1.6e-4 + 1e-6 * rank, "guard_reruns": rank}   # (figures outside ARITH_KEYS may differ)
     if differ and rank == 1:
         arith["exact"], arith["w2_units"] = 3, 0xC   # this rank's calibration chose hi+lo weights in layer1
     try:
