@@ -156,12 +156,13 @@ struct GuardSlot {
   int32_t *d_flat = nullptr, *d_idx = nullptr, *d_count = nullptr;
   float *d_lg = nullptr;       // logits for the margin test when the caller wants none
   float *d_mag = nullptr;      // per-CU logit magnitude (HeadArgs.mag) for the magnitude guard
+  int32_t *d_ticket = nullptr; // two words, zero between launches: finished workgroups / running count of the selection fused into the heads kernel (HeadArgs.g_ticket)
   int32_t *h_count = nullptr;  // pinned
   bool single = false;         // mlt_predict's slot: one CU, d_flat zero on entry and cleared by the heads kernel (consume-and-clear), the
                                // selection rides on the heads kernel, and the caller's own result copy brings the count back
 };
 // guard selection fused into the heads kernel of a single-CU launch (HeadArgs.g_*)
-struct GuardTail { int32_t *count, *idx, *flat; int flat_thr, near_thr; float margin, mag_thr; };
+struct GuardTail { int32_t *count, *idx, *flat; int flat_thr, near_thr; float margin, mag_thr; int32_t *ticket; };  // ticket != NULL: batches (HeadArgs.g_ticket)
 
 // mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
 // hipGraph captured once per CU size, one D2H.
@@ -234,6 +235,8 @@ struct mlt_ctx {
   size_t gstage_bytes = 0;
   std::string err;
   bool profile = false;
+  bool guard_select_kernel = false;  // MLT_GUARD_SELECT_KERNEL (read at mlt_init, like MLT_CHUNK): the guards' selection of a BATCH as a launch of its own (round 5's form,
+                                     // ascending list) instead of a tail of the heads kernel -- kept for the A/B and the bit-identity test
   bool lds_oob_zero = false;  // DS reads beyond the LDS allocation return zeros on this device (probed at init): chain kernels without zero masks
   std::map<std::string, ProfAcc> prof;
   std::vector<std::string> prof_order;
@@ -849,7 +852,8 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
   }
   ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
   ha.mag = d_mag;
-  if (tail && n == 1) {
+  if (tail && (n == 1 || tail->ticket)) {
+    ha.g_ticket = n == 1 ? nullptr : tail->ticket;
     ha.g_count = tail->count; ha.g_idx = tail->idx; ha.g_flat = tail->flat; ha.g_flat_thr = tail->flat_thr; ha.g_near_thr = tail->near_thr; ha.g_margin = tail->margin;
     ha.g_mag_thr = tail->mag_thr;
   }
@@ -893,12 +897,14 @@ int guard_slot(mlt_ctx *ctx, int which, int n, int nl, GuardSlot *g) {
     const size_t ints = ((size_t)cn * 4 + 255) / 256 * 256;
     ctx->guard_slot_bytes = 3 * ints + 256 + ((size_t)cn * cl * 4 + 255) / 256 * 256;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->guard_dev, 2 * ctx->guard_slot_bytes));
+    HIP_TRY(ctx, hipMemset(ctx->guard_dev, 0, 2 * ctx->guard_slot_bytes));   // (the selection's ticket words must start at zero)
     ctx->guard_cap_n = cn; ctx->guard_cap_nl = cl;
   }
   if (!ctx->guard_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->guard_host, 64, hipHostMallocDefault));
   const size_t ints = ((size_t)ctx->guard_cap_n * 4 + 255) / 256 * 256;
   char *base = ctx->guard_dev + (size_t)which * ctx->guard_slot_bytes;
   g->d_flat = (int32_t *)base; g->d_idx = (int32_t *)(base + ints); g->d_count = (int32_t *)(base + 2 * ints);
+  g->d_ticket = g->d_count + 8;   // (inside the 256 bytes reserved for the count)
   g->d_lg = (float *)(base + 2 * ints + 256);
   g->d_mag = (float *)(base + 2 * ints + 256 + ((size_t)ctx->guard_cap_n * ctx->guard_cap_nl * 4 + 255) / 256 * 256);
   g->h_count = ctx->guard_host + which;
@@ -932,8 +938,17 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
     // one CU (mlt_predict's captured graph): the selection is a tail of the heads kernel -- no guard_select launch, no memset of the
     // statistic (the tail clears it for the next call; it is only consumed when the first kernel is the one that produces it: aligned planes,
     // S >= 64 -- else flat_stat_kernel overwrites it), no separate copy of the count (the caller's result copy carries it)
-    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr};
+    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, nullptr};
     return run_main(ctx, st, 1, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg, st.flat_guard ? g.d_flat : nullptr, &tail, true);
+  }
+  if (!ctx->guard_select_kernel && g.d_ticket) {
+    // round 6: the selection is a tail of the heads kernel for batches as well (unordered list of flagged CUs through an atomic append, the count published by
+    // the last workgroup): one launch and one launch gap less per step
+    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, g.d_ticket};
+    if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
+                       st.flat_guard ? g.d_flat : nullptr, &tail))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(g.h_count, g.d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return MLT_OK;
   }
   float *mg = st.mag_thr > 0.f ? g.d_mag : nullptr;
   if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
@@ -1870,6 +1885,7 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
   ctx->guard_margin = cfg->guard_margin > 0.f ? cfg->guard_margin : 3.f * ctx->tolerance;
   ctx->guard_margin_configured = cfg->guard_margin > 0.f;
   if (const char *e = tuning_env("MLT_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->chunk = v; }
+  ctx->guard_select_kernel = tuning_env("MLT_GUARD_SELECT_KERNEL") != nullptr;
   if (const char *e = tuning_env("MLT_STAGE_CHUNK")) { int v = std::atoi(e); if (v > 0) ctx->stage_chunk = v; }
   if (ctx->stage_chunk > ctx->chunk) ctx->stage_chunk = ctx->chunk;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_init_error = "hipStreamCreate failed"; delete ctx; return MLT_ERR_HIP; }
@@ -2275,11 +2291,12 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
 // ---- deferred single-CU prediction ----
 namespace {
 // device / pinned layout of one output set: split[CAP] | logits[CAP * nl] | flagged count (16 ints) | flat[CAP] | idx[CAP]
-struct DeferredOut { int32_t *split; float *lg; int32_t *count, *flat, *idx; float *mag; };
+struct DeferredOut { int32_t *split; float *lg; int32_t *count, *ticket, *flat, *idx; float *mag; };
 DeferredOut deferred_out(char *base, int nl) {
   DeferredOut o;
   o.split = (int32_t *)base; o.lg = (float *)(base + (size_t)MLT_DEFER_CAP * 4);
   o.count = (int32_t *)(base + (size_t)MLT_DEFER_CAP * 4 * (1 + nl));
+  o.ticket = o.count + 8;   // (inside the 16 ints reserved for the count; BEHIND the bytes mlt_wait fetches, deferred_fetch_bytes: + 64 covers the 16 ints)
   o.flat = o.count + 16; o.idx = o.flat + MLT_DEFER_CAP; o.mag = (float *)(o.idx + MLT_DEFER_CAP);
   return o;
 }
@@ -2301,7 +2318,7 @@ int deferred_launch(mlt_ctx *ctx, SizeState *st, Deferred &df) {  // launch the 
   int rc;
   if (st->guards()) {
     GuardSlot g;
-    g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.d_mag = od.mag; g.h_count = oh.count;
+    g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.d_mag = od.mag; g.d_ticket = od.ticket; g.h_count = oh.count;
     rc = run_guarded_async(ctx, *st, n, pl, d_poc, d_qp, od.split, od.lg, g);
     df.guard_pending[b] = true;
   } else {
@@ -2370,6 +2387,7 @@ int mlt_submit(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t *
     HIP_TRY(ctx, hipHostMalloc((void **)&df.h_out, 2 * df.out_set, hipHostMallocDefault));
     HIP_TRY(ctx, hipMalloc((void **)&df.d_in, 2 * df.in_set));
     HIP_TRY(ctx, hipMalloc((void **)&df.d_out, 2 * df.out_set));
+    HIP_TRY(ctx, hipMemset(df.d_out, 0, 2 * df.out_set));   // (the selection's ticket words start at zero)
     for (int b = 0; b < 2; ++b) HIP_TRY(ctx, hipEventCreateWithFlags(&df.done[b], hipEventDisableTiming));
   }
   if (df.n == MLT_DEFER_CAP && (rc = deferred_launch(ctx, st, df))) return rc;  // full: flush, start the next generation

@@ -193,6 +193,11 @@ struct HeadArgs {
   // wanted.  g_mag_thr > 0 (single-CU launches): CU 0 is also flagged when its magnitude exceeds the threshold (NaN included).
   float *mag;
   float g_mag_thr;
+  // Round 6: the selection rides on this kernel for BATCHES too (g_ticket != NULL; guard_select_kernel -- a launch of its own, 23 us + a launch gap of a 4 ms step --
+  // stays behind MLT_TUNING=1 MLT_GUARD_SELECT_KERNEL=1).  Every workgroup tests its CU and appends it to g_idx through g_ticket[1] (a running count; the list is
+  // UNORDERED -- the exact re-run treats every CU independently, so the results do not depend on the order); the last workgroup to finish (g_ticket[0] counts them)
+  // publishes the count in g_count[0] and zeroes both words for the next launch (they start at zero: the runtime clears them when it allocates the slot).
+  int32_t *g_ticket;
 };
 
 // ---- parity guard (fast arithmetic): device-side selection of the CUs that are re-evaluated with the exact arithmetic ----

@@ -48,26 +48,28 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_traff
                        os.path.join(run, "fetch", "out_counter_collection.csv"), os.path.join(run, "write", "out_counter_collection.csv"),
                        "4096", os.path.join(prof, "pmc_traffic.json"), tag, sig], stdout=subprocess.DEVNULL)
 shutil.copy(os.path.join(prof, "pmc_traffic.json"), os.path.join(prof, f"{tag}_pmc_traffic.json"))
-rows = collections.defaultdict(dict)
-for d in sorted(glob.glob(os.path.join(run, "pmc", "*/"))):
-    f = os.path.join(d, "out_counter_collection.csv")
-    if not os.path.exists(f):
-        continue
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0)):
-        k = r["Kernel_Name"]
-        if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k or "layer0_" in k or "layer1_" in k:
-            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        for c, x in v.items():
-            x = x[-STEPS:]  # the batch launches come last; the load-time calibration runs the same kernels on 16-CU sub-batches first
-            rows[k][c] = sum(x) / len(x)
-if rows:
+def sq_summary(pmc_dir, out_path, header, last):
+    """One line per kernel from the per-group counter passes under pmc_dir; last = dispatches per kernel to average (None: all of them)."""
+    rows = collections.defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(pmc_dir, "*/"))):
+        f = os.path.join(d, "out_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0) or 0)):
+            k = r["Kernel_Name"]
+            if "conv_" in k or "block" in k or "heads" in k or "chain_" in k or "guard_" in k or "flat_stat" in k or "layer0_" in k or "layer1_" in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            for c, x in v.items():
+                x = x[-last:] if last else x  # the batch launches come last; the load-time calibration runs the same kernels on 16-CU sub-batches first
+                rows[k][c] = sum(x) / len(x)
+    if not rows:
+        return
     cols = ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS",
             "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY"]
-    with open(os.path.join(prof, f"{tag}_pmc_sq_summary.txt"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 scripts/prof_run.py 4096 2  (one pass per counter group, MI355X)\n")
-        o.write("# per-kernel average over the LAST 2 dispatches (the 4096-CU batches; calibration launches excluded); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs\n")
+    with open(out_path, "w") as o:
+        o.write(header)
         o.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); lds_busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE/8 * 256 CUs)\n")
         o.write("kernel," + ",".join(cols) + ",mfma_util,lds_busy_frac,lds_conflict_frac\n")
         for k, v in rows.items():
@@ -75,6 +77,16 @@ if rows:
             mu = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * 1024) if g else 0
             lb = v.get("SQ_LDS_IDX_ACTIVE", 0) / (g * 256) if g else 0
             lc = v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"] if v.get("SQ_LDS_IDX_ACTIVE") else 0
-            short = k.replace("void ", "").split("(")[0][:72]
+            short = k.replace("void ", "").split("(")[0][:96]
             o.write('"%s",' % short + ",".join("%.4g" % v.get(c, 0) for c in cols) + ",%.3f,%.3f,%.3f\n" % (mu, lb, lc))
+
+
+sq_summary(os.path.join(run, "pmc"), os.path.join(prof, f"{tag}_pmc_sq_summary.txt"),
+           "# rocprofv3 --kernel-trace --pmc <counters> -- python3 scripts/prof_run.py 4096 2  (one pass per counter group, MI355X)\n"
+           "# per-kernel average over the LAST 2 dispatches (the 4096-CU batches; calibration launches excluded); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs\n", STEPS)
+# round 6: the EXACT arithmetic's per-conv launches (configured exact: no calibration, every dispatch is a 2048-CU batch launch; a kernel runs several layers of one
+# shape per step -- the line is the average over all of them)
+sq_summary(os.path.join(run, "pmc_exact"), os.path.join(prof, f"{tag}_pmc_sq_summary_exact.txt"),
+           "# rocprofv3 --kernel-trace --pmc <counters> -- python3 scripts/prof_run.py 2048 2 1  (MLT_FLAG_EXACT_128; one pass per counter group, MI355X)\n"
+           "# per-kernel average over ALL dispatches (no calibration in this configuration); SQ_* summed over the chip; GRBM_GUI_ACTIVE summed over the 8 XCDs\n", None)
 print("wrote profiles/%s_*" % tag)

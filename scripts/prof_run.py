@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3: runs the 128x128 hot path a few times on a fixed batch (no torch.distributed,
-no oracle) so per-kernel counters are easy to read.  usage: prof_run.py [batch] [steps]"""
+no oracle) so per-kernel counters are easy to read.  usage: prof_run.py [batch] [steps] [flags, e.g. 1 = the exact arithmetic]"""
 import os
 import sys
 
@@ -13,10 +13,11 @@ import mltcnn_pkg
 pkg = mltcnn_pkg.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+flags = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 size = 128
 dev = torch.device("cuda", 0)
 blob = pkg.weights.synthetic_blob(0, 10)
-m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, max_batch=B)
+m = pkg.MltCnn(device=0, sizes=(size,), blobs={size: blob}, max_batch=B, flags=flags)
 org, pred = pkg.synth.make_patches_bulk(size, B, 0xC0FFEE)
 poc, qp = pkg.synth.make_scalars(B, 0xC0FFEE)
 d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]

@@ -86,7 +86,7 @@ if "--markdown" in sys.argv:
     print(f"| roofline kernel {r['kernel']} | {r['avg_launch_ms']:.3f} ms (HIP events; rocprofv3 batch launches {batch_ms:.3f} ms) = {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f}; SQ_VALU_MFMA_BUSY {100 * float(sq.get('mfma_util', 0)):.1f} %, bank conflicts {100 * float(sq.get('lds_conflict_frac', 0)):.1f} %; PMC traffic {next(v['hbm_bytes_per_launch'] for n, v in json.load(open(os.path.join(P, f'{tag}_pmc_traffic.json'))).items() if n.startswith(r['kernel'].split('(')[0])) / 1e9:.2f} GB vs {r['algo_bytes_per_launch'] / 1e9:.2f} GB |")
     front = (f"layer0 + layer1.0.conv1 streamed {ms('layer0_stream'):.3f} ({rf('layer0_stream'):.2f})" if any(n.startswith("layer0_stream") for n in km) else
              f"layer0.0 {ms('stem+block'):.3f} ({rf('stem+block'):.2f}) . layer0.1 {ms('block_s1'):.3f} ({rf('block_s1'):.2f}) . 32->64 s2 {ms('conv3x3_s2_32to64'):.3f} ({rf('conv3x3_s2_32to64'):.2f})")
-    print(f"| other launches | {front} . 64-channel stage {ms('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.3f} ({rf('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.2f}) . layer3 {ms('stage_256'):.3f} ({rf('stage_256'):.2f}) . heads {ms('heads'):.3f} . guard select {ms('guard_select'):.3f} |")
+    print(f"| other launches | {front} . 64-channel stage {ms('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.3f} ({rf('layer1_stream' if any(n.startswith('layer1_stream') for n in km) else 'chain3_s1_64'):.2f}) . layer3 {ms('stage_256'):.3f} ({rf('stage_256'):.2f}) . heads {ms('heads'):.3f}" + (f" . guard select {ms('guard_select'):.3f}" if any(n.startswith('guard_select') for n in km) else " (with the guards' selection)") + " |")
     print(f"| whole path | {dv['whole_path']['t_bound_ms']:.3f} / {dv['whole_path']['t_measured_ms']:.3f} = {dv['whole_path']['frac']:.2f}; HBM layer-wise fraction {dv['hbm_layerwise_roofline_frac']:.2f} |")
     print(f"| decision guard | {dg['value'] / 1e3:.0f} k |")
     print("| other weight sets | " + " . ".join(f"{n}: {seeds[n]['value'] / 1e3:.0f} k ({seeds[n]['parity']['max_abs_dlogit']:.1e})" for n in (23, 24, 13, 11, 21, 25, 12, 22) if n in seeds) + f" . exact: {ex['value'] / 1e3:.0f} k |")

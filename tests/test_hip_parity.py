@@ -1138,6 +1138,52 @@ def test_layer0_stream_under_the_other_tiers(gpu, seed):
     m.close()
 
 
+def test_guard_selection_in_heads_kernel_matches_select_kernel(gpu, monkeypatch):
+    """Round 6: a batch's guard selection (flat content, decision margin, logit magnitude) is a tail of the heads kernel -- an unordered list through an
+    atomic append, the count published by the last workgroup, both words re-armed for the next launch -- instead of a launch of its own
+    (MLT_GUARD_SELECT_KERNEL=1 under MLT_TUNING=1: round 5's guard_select_kernel, ascending list).  Same CUs selected, same bits, on repeated calls of
+    different sizes (the ticket words must come back to zero every time), through the batch, device-pointer and deferred entry points."""
+    pkg = gpu
+    size = 128
+    blob = pkg.weights.synthetic_blob(0, 10)
+    n = 300
+    ot, pt = pkg.synth.make_patches_bulk(size, n - 90, 9201)
+    of, pf = pkg.synth.make_patches(size, 40, 9202, pkg.synth.KIND_FLAT)
+    on, pn = pkg.synth.natural_patches(size, 50, 9203)
+    org = np.concatenate([ot, of, on]); pred = np.concatenate([pt, pf, pn])
+    perm = np.random.default_rng(9204).permutation(n)
+    org, pred = org[perm], pred[perm]
+    poc, qp = pkg.synth.make_scalars(n, 9205)
+    fused = _ctx(pkg, size, blob, max_batch=n)
+    monkeypatch.setenv("MLT_TUNING", "1")
+    monkeypatch.setenv("MLT_GUARD_SELECT_KERNEL", "1")
+    plain = _ctx(pkg, size, blob, max_batch=n)
+    monkeypatch.delenv("MLT_GUARD_SELECT_KERNEL")
+    for k in (n, 129, 300, 17, 2, 256):   # (repeats and shrinking / growing batches: a stale ticket or count would show as a wrong number of re-runs)
+        rf, rp = fused.arithmetic(size)["guard_reruns"], plain.arithmetic(size)["guard_reruns"]
+        sf, lf = fused.predict_batch(org[:k], pred[:k], poc[:k], qp[:k])
+        sp, lp = plain.predict_batch(org[:k], pred[:k], poc[:k], qp[:k])
+        rf, rp = fused.arithmetic(size)["guard_reruns"] - rf, plain.arithmetic(size)["guard_reruns"] - rp
+        assert rf == rp and (k < 100 or rf > 0), (k, rf, rp)
+        assert np.array_equal(sf, sp) and np.array_equal(lf, lp), k
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (org, pred, poc, qp)]
+    d_split = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    d_lg = torch.zeros((n, 9), dtype=torch.float32, device=dev)
+    s_all, l_all = plain.predict_batch(org, pred, poc, qp)
+    for _ in range(3):
+        fused.predict_batch_device(n, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_lg.data_ptr())
+        fused.synchronize()
+        assert np.array_equal(d_split.cpu().numpy(), s_all) and np.array_equal(d_lg.cpu().numpy(), l_all)
+    for lo in (0, 20, 150):   # deferred generations of 24 CUs
+        tk = [fused.submit(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(lo, lo + 24)]
+        fused.flush(size)
+        for j, t in enumerate(tk):
+            s1, l1 = fused.wait(size, t)
+            assert s1 == s_all[lo + j] and np.array_equal(l1, l_all[lo + j]), ("deferred", lo + j)
+    fused.close(); plain.close()
+
+
 def test_magnitude_guard(gpu):
     """Round 6.  A weight set that amplifies the residual plane -- what training leaves behind; here the deterministic stand-in
     weights.amplifying_blob -- has logits, and absolute fp16 errors, many times larger on content with huge residuals (the calibration classes
