@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -89,8 +90,35 @@ int size_index(int size) {
 }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// One launch of a size's plan (built by plan_network, walked by run_network -- both further down): the kind says which buffers it reads and writes.
+struct PlanStep {
+  enum Kind : uint8_t {
+    FLAT_STAT,      // the flat-content statistic as a launch of its own (the first kernel does not read the raw planes as aligned quads)
+    LAYER0_STREAM,  // all of layer0 (front: + layer1.0.conv1 + shortcut) from the raw planes          -> out[0] | t = pool0, sc = pool1 (chunk-major)
+    STEM_BLOCK,     // layer0.0 from the raw planes                                                      -> b0 = pool2
+    STEM5,          // composed first layer: t, sc of layer0.0                                           -> pool0, pool1
+    CONV_S2,        // stride-2 conv + shortcut that open stage s: stage input                           -> t = pool0, sc = pool1
+    CHAIN,          // rest of stage s (inside_s2: all of it, from the stage input) in one launch        -> out[s] (+ GAP)
+    LAYER1_STREAM,  // the three stride-1 convs of the 64-channel stage, streaming form                   -> out[1] (+ GAP)
+    CONV_B0C2,      // block 0, conv2 + shortcut + ReLU: pool0, pool1                                     -> b0 = pool2
+    BLOCK32,        // layer0.1 in one kernel: pool2                                                      -> out[0]
+    CONV_B1C1,      // block 1, conv1: pool2                                                              -> pool3
+    CONV_B1C2,      // block 1, conv2 + b0 + ReLU: pool3, pool2                                           -> out[s] (+ GAP)
+    HEADS
+  } kind;
+  int8_t s = 0;             // stage
+  bool front = false;       // LAYER0_STREAM: layer1.0.conv1 + shortcut ride along
+  bool inside_s2 = false;   // CHAIN: the stage's stride-2 conv + shortcut run inside the launch
+  bool x_c16 = false;       // CHAIN (inside_s2): the stage input is chunk-major
+  bool sc_c16 = false;      // CONV_S2 writes / CHAIN, LAYER1_STREAM read the shortcut chunk-major
+  bool y_c16 = false;       // the stage's output is written chunk-major (its consumer is a whole-stage launch)
+};
+using NetPlan = std::vector<PlanStep>;
+using PlanKey = std::tuple<const void *, const void *, const void *, unsigned, unsigned, unsigned>;   // models (main, hi+lo weights, exact), their unit masks, batch class
+
 struct SizeState {
   bool enabled = false, loaded = false;
+  std::map<PlanKey, NetPlan> plans;   // launch plans of the loaded tier, by batch class (filled on first use; cleared by every (re)load)
   bool exact = false;          // arithmetic `model` runs (after calibration)
   bool w2 = false;             // middle tier: the main path runs `model_w2` (hi+lo weights on single fp16 activations, fused kernels); guards as for fast
   unsigned w2_mask = 0;        // ... in the stages whose bit is set (bit s = layer s; all four: the whole network); the other stages stay on the
@@ -156,13 +184,14 @@ struct GuardSlot {
   int32_t *d_flat = nullptr, *d_idx = nullptr, *d_count = nullptr;
   float *d_lg = nullptr;       // logits for the margin test when the caller wants none
   float *d_mag = nullptr;      // per-CU logit magnitude (HeadArgs.mag) for the magnitude guard
-  int32_t *d_ticket = nullptr; // two words, zero between launches: finished workgroups / running count of the selection fused into the heads kernel (HeadArgs.g_ticket)
+  int *phase = nullptr;        // batches with the selection inside the heads kernel: d_count[*phase] is the launch's running count (zero on entry), d_count[*phase ^ 1] the
+                               // one it zeroes for the NEXT launch of the slot; toggled per launch (run_guarded_async).  NULL: no such pair (the slot serves one-CU launches)
   int32_t *h_count = nullptr;  // pinned
   bool single = false;         // mlt_predict's slot: one CU, d_flat zero on entry and cleared by the heads kernel (consume-and-clear), the
                                // selection rides on the heads kernel, and the caller's own result copy brings the count back
 };
 // guard selection fused into the heads kernel of a single-CU launch (HeadArgs.g_*)
-struct GuardTail { int32_t *count, *idx, *flat; int flat_thr, near_thr; float margin, mag_thr; int32_t *ticket; };  // ticket != NULL: batches (HeadArgs.g_ticket)
+struct GuardTail { int32_t *count, *idx, *flat; int flat_thr, near_thr; float margin, mag_thr; int32_t *next; };  // next != NULL: batches (HeadArgs.g_next)
 
 // mlt_predict (one CU per call, the encoder's use): pinned host staging, one H2D, the kernel chain replayed from a
 // hipGraph captured once per CU size, one D2H.
@@ -187,6 +216,7 @@ struct Deferred {
   uint64_t gen_of_set[2] = {~0ull, ~0ull};
   hipEvent_t done[2] = {nullptr, nullptr};
   bool guard_pending[2] = {false, false};   // set's batch ran with guards and its flagged CUs have not been re-evaluated yet
+  int phase[2] = {0, 0};                    // which of the set's two selection counters (count[0 .. 1]) its next launch counts on (GuardSlot.phase)
 };
 
 struct ProfAcc { uint32_t launches = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
@@ -230,6 +260,7 @@ struct mlt_ctx {
   size_t guard_slot_bytes = 0;
   int guard_cap_n = 0, guard_cap_nl = 0;
   int32_t *guard_host = nullptr;  // pinned: two counters
+  int guard_phase[2] = {0, 0};    // which counter of a slot's pair the next batch launch counts on (GuardSlot.phase)
   hipEvent_t ev_guard = nullptr;  // "count of flagged CUs has landed" (device-pointer entry)
   char *gstage = nullptr;
   size_t gstage_bytes = 0;
@@ -244,6 +275,7 @@ struct mlt_ctx {
   // RECORDS every launch (name + variant) here instead of enqueuing it, touches no device and allocates nothing: what a batch of n CUs of a tier
   // would launch, observable and unit-tested on the CPU (mlt_plan_describe, tests/test_launch_plan_cpu.py).
   std::vector<std::string> *plan = nullptr;
+  bool plan_detail = false;   // ... with the buffers of every launch (offsets into the workspace, which plan mode carves from address 0): the hand-offs between launches
 };
 
 namespace {
@@ -374,6 +406,24 @@ struct Launch {
   }
 };
 
+// plan mode with detail: append the launch's buffers to its record ("{x=ws+0x..., y=...}"; NULL pointers are left out, workspace pointers print as offsets)
+void plan_note(mlt_ctx *ctx, std::initializer_list<std::pair<const char *, const void *>> ptrs, std::initializer_list<std::pair<const char *, long>> vals = {}) {
+  if (!ctx->plan || !ctx->plan_detail || ctx->plan->empty()) return;
+  std::string t = " {";
+  char b[64];
+  bool first = true;
+  for (const auto &q : ptrs) {
+    if (!q.second) continue;
+    std::snprintf(b, sizeof b, "%s%s=0x%llx", first ? "" : " ", q.first, (unsigned long long)(uintptr_t)q.second);
+    t += b; first = false;
+  }
+  for (const auto &q : vals) {
+    std::snprintf(b, sizeof b, "%s%s=%ld", first ? "" : " ", q.first, q.second);
+    t += b; first = false;
+  }
+  ctx->plan->back() += t + "}";
+}
+
 struct ConvIO {
   const void *x = nullptr;    // input activation (ignored when raw planes are given)
   void *y = nullptr;          // main output (may be NULL when only the GAP sums are needed)
@@ -470,6 +520,8 @@ int run_conv(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int hin, const Conv
                 io.y_c16 ? ", y chunk-major" : "", io.ysc_c16 ? ", sc chunk-major" : "", io.gap ? ", GAP" : "");
   int rc = L.prof_begin(name, flops, bytes, e0, e1, variant);
   if (rc) return rc;
+  plan_note(ctx, {{"x", io.x}, {"y", io.y}, {"y_sc", io.y_sc}, {"res", io.res}, {"gap", io.gap}},
+            {{"x_lo", (long)io.x_lo}, {"y_lo", (long)io.y_lo}, {"res_lo", (long)io.res_lo}, {"ysc_lo", (long)io.ysc_lo}, {"relu", io.relu}, {"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_conv(pc.cin, pc.cout, pc.stride, nsplit, pc.taps == 1 ? MLT_CONV_CENTRE : lat ? MLT_CONV_LATENCY : dma ? MLT_CONV_DMA : MLT_CONV_DEFAULT, a, grid_x, extra_lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (io.y && (rc = debug_dump(ctx, name, io.y, (size_t)px * pc.cout * 2))) return rc;
@@ -503,6 +555,7 @@ int run_stem5(mlt_ctx *ctx, const mlt::PackedConv &pc, int n, int S, const int16
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18), (double)n * S * S * 4 + px * 32 * 2 * 2, e0, e1, pc.xl ? "exact-lite" : pc.exact ? "exact" : pc.w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
+  plan_note(ctx, {{"y", y}, {"y_sc", y_sc}}, {{"lo", (long)lo_off}, {"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_stem5(a, pc.exact ? 2 : pc.w2 ? 3 : 1, grid_x, lds, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if ((rc = debug_dump(ctx, name, y, (size_t)px * 32 * 2))) return rc;
@@ -530,6 +583,7 @@ int run_stem_block(mlt_ctx *ctx, const mlt::Model &m, int n, int S, const int16_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * (50 + 18 + 288), (double)n * S * S * 4 + px * 32 * 2, e0, e1, m.w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
+  plan_note(ctx, {{"y", y}, {"flat", d_flat}}, {{"flat_is_clear", flat_is_clear}, {"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_stem_block(a, m.w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
@@ -558,6 +612,7 @@ int run_layer0_stream(mlt_ctx *ctx, const mlt::Model &m0, const mlt::Model &m1, 
               : L.prof_begin("layer0_stream_h64(stem+layer0.0+layer0.1)", 2.0 * px * 32 * (50 + 18 + 3 * 288), (double)n * 128 * 128 * 4 + px * 32 * 2, e0, e1);
   if (rc) return rc;
   const bool mfma32 = tuning().l0_mfma32;   // round 5's MFMA shape (A/B; the results are the same bits)
+  plan_note(ctx, {{"y", c5 ? nullptr : y}, {"y_t", c5 ? y_t : nullptr}, {"y_sc", c5 ? y_sc : nullptr}, {"flat", d_flat}}, {{"flat_is_clear", flat_is_clear}, {"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_layer0_stream(a, c5 != nullptr, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (c5) {
@@ -583,6 +638,7 @@ int run_block32(mlt_ctx *ctx, const mlt::Block &B, int n, int h, const void *x, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = L.prof_begin(name, 2.0 * px * 32 * 32 * 9 * 2, px * 32 * 2 * 2 + 2.0 * 18 * 1024, e0, e1, w2 ? "hi+lo weights" : "single pass");
   if (rc) return rc;
+  plan_note(ctx, {{"x", x}, {"y", y}}, {{"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_block32(a, w2, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, name, y, (size_t)px * 32 * 2);
@@ -632,6 +688,7 @@ int run_chain3(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, int n, 
                 gap ? ", GAP" : "");
   int rc = L.prof_begin(name, flops, bytes, e0, e1, variant);
   if (rc) return rc;
+  plan_note(ctx, {{"x", a.x}, {"sc", s2_in ? nullptr : sc}, {"y", y}, {"gap", gap}, {"b0", c == 64 ? b0_hbm : nullptr}}, {{"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_chain(c, h, s2_in != nullptr, ctx->lds_oob_zero, w2, a, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   if (y && (rc = debug_dump(ctx, name, y, (size_t)px * c * 2))) return rc;
@@ -656,9 +713,123 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
   // profiles/r06e_mfma16_ab.txt) -- the bare loop's +11 % is a clock effect at 1.6 GHz, this kernel already holds ~2.1 GHz and pays for twice the MFMA issue
   // slots and 8-byte epilogue accesses: it stays on 32x32x16 (MLT_TUNING=1 MLT_L1_MFMA16=1 selects the other form)
   const bool mfma32 = tuning().l1_mfma32;
+  plan_note(ctx, {{"t", t}, {"sc", sc}, {"y", y}, {"gap", gap}}, {{"grid", grid_x}});
   LAUNCH_TRY(ctx, mlt_launch_layer1_stream(a, mfma32, grid_x, ctx->stream));
   if ((rc = L.prof_end(e1))) return rc;
   return debug_dump(ctx, "chain3_s1_64_h32(conv2+conv1+conv2)", y, (size_t)px * 64 * 2);
+}
+
+// ---- launch plans (round 6) ----
+// WHAT a batch launches is decided once per (size, tier, batch class, alignment) -- plan_network, a pure function of the models' packing, the tier's
+// launch-unit masks and a handful of booleans derived from n and the planes' alignment -- and cached in the size's state; the hot path (run_network)
+// binds the workspace and walks the list.  mlt_plan_describe shows the walk on the CPU (tests/test_launch_plan_cpu.py, scripts/plan_matrix.py).
+struct NetCfg {   // the arithmetic of a pass: every launch unit takes its weights from one of up to three models
+  int S = 0;
+  mlt::Model *m = nullptr, *mback = nullptr, *mx = nullptr;   // main | hi+lo weights for the units of back_mask | exact for the units of x_units
+  unsigned back_mask = 0, x_units = 0;
+  mlt::Model &model_of(int s, int u) const { return ((x_units >> (2 * s + u)) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : *m; }
+  int h_in(int s) const { int h = S; for (int i = 0; i < s; ++i) h = h / 2 > 0 ? h / 2 : 1; return h; }   // map side at the input of stage s
+};
+// the batch class: everything about a CALL that the choice of launches depends on
+enum : unsigned { CLS_QUADS = 1u, CLS_FLAT = 2u, CLS_L0_STREAM = 4u, CLS_L1_STREAM = 8u, CLS_CHAIN0 = 16u /* << s: stage s is large enough for a whole-stage launch */ };
+unsigned batch_class(const mlt_ctx *ctx, const NetCfg &c, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred, long pred_rs, long pred_cs, bool has_flat) {
+  (void)ctx;
+  const Tuning &tn = tuning();
+  unsigned cls = 0;
+  // stem_block_kernel / layer0_stream_kernel fetch 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
+  if ((((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0) cls |= CLS_QUADS;
+  if (has_flat) cls |= CLS_FLAT;
+  // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch; round 6: from 128 CUs on -- the measured crossover (docs/KERNEL_NOTES.md,
+  // "Where the streaming launches start to pay": 128 CUs +3 %, 192 CUs +12 %); the same for layer1's three stride-1 convs
+  if (tn.l0_stream_min > 0 && n >= tn.l0_stream_min) cls |= CLS_L0_STREAM;
+  if (tn.l1_stream_min > 0 && n >= tn.l1_stream_min) cls |= CLS_L1_STREAM;
+  for (int s = 1; s < c.m->n_stages; ++s) {   // small launches keep the per-conv latency variants: a chain runs its convs one after the other on n workgroups
+    const int h = c.h_in(s), ho = h / 2 > 0 ? h / 2 : 1;
+    if ((long)n * ho * ho > tn.lat_pixels) cls |= CLS_CHAIN0 << s;
+  }
+  return cls;
+}
+
+
+NetPlan plan_network(const mlt_ctx *ctx, const NetCfg &c, unsigned cls) {
+  const Tuning &tn = tuning();
+  const mlt::Model &m = *c.m;
+  NetPlan P;
+  auto add = [&](PlanStep::Kind k, int s) -> PlanStep & { PlanStep st{}; st.kind = k; st.s = (int8_t)s; P.push_back(st); return P.back(); };
+  // Which stages run as chain / whole-stage launches (fast arithmetic, large launches).  Asked for stage s AND for stage s + 1: a stage whose successor
+  // is a whole-stage kernel writes its output chunk-major (ConvArgs.y_c16).
+  auto wants_chain = [&](int s) -> bool {
+    if (s <= 0 || s >= m.n_stages || tn.no_chain || !(cls & (CLS_CHAIN0 << s))) return false;
+    const mlt::Model &mm = c.model_of(s, 1);
+    if (mm.exact || (mm.w2 && !ctx->lds_oob_zero)) return false;  // (the hi+lo-weights chains exist in the padding-from-beyond-the-LDS form only)
+    const int h = c.h_in(s), ho = h / 2 > 0 ? h / 2 : 1;
+    const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
+    // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
+    // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
+    const bool packing_ok = (m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && tn.chain64) : (c2.ct == 128 && c2.gt == 3)) && (!mm.w2 || c2.lo8 || m.planes[s] == 64);  // what chain_kernel<C> streams
+    return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok;
+  };
+  // (the whole-stage form -- stride-2 conv + shortcut inside the launch -- exists for the single pass only: both units of the stage on `m`)
+  auto wants_s2 = [&](int s) -> bool {
+    if (!wants_chain(s) || tn.no_chain_s2 || c.model_of(s, 0).w2 || c.model_of(s, 1).w2) return false;
+    const mlt::PackedConv &p2 = c.model_of(s, 0).blocks[s][0].conv1_s2c;
+    return ctx->plan ? !p2.w.empty() : p2.d_w != nullptr;
+  };
+  bool cur_c16 = false;    // layout of the stage input
+  bool l0_front = false;   // the layer0 streaming launch carried layer1.0.conv1 + shortcut
+  for (int s = 0; s < m.n_stages; ++s) {
+    const bool last = s == m.n_stages - 1;
+    const mlt::Model &ms = c.model_of(s, 0);  // first launch unit: layer0.0 / the stride-2 conv + shortcut
+    const mlt::Model &mt = c.model_of(s, 1);  // second unit: layer0.1, or conv2 of block 0 + block 1 of the later stages
+    const int h = c.h_in(s), ho = h / 2 > 0 ? h / 2 : 1;
+    const bool fused_b0 = s == 0 && !ms.exact && ho >= 32 && !tn.no_block_fusion && (cls & CLS_QUADS);
+    if (s == 0 && (cls & CLS_FLAT) && !fused_b0) add(PlanStep::FLAT_STAT, 0);
+    if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && (cls & CLS_L0_STREAM)) {
+      // ... and with it the stride-2 conv + shortcut that open layer1, when the 64-channel chain follows (it wants sc chunk-major) and layer1's first
+      // unit runs the single pass too: layer0's output then never reaches HBM
+      const mlt::Model &m10 = c.model_of(1, 0);
+      const mlt::PackedConv &c5 = m10.blocks[1][0].conv1;
+      l0_front = !tn.no_l0_s5 && m.n_stages > 1 && !m10.exact && !m10.w2 && wants_chain(1) && !wants_s2(1) && m.planes[1] == 64 && !tn.no_c16 &&
+                 c5.has_sc && c5.taps == 9 && c5.kc == 32 && c5.ct == 64 && c5.cin == 32 && c5.cout == 64 && c5.stride == 2;
+      add(PlanStep::LAYER0_STREAM, 0).front = l0_front;
+      continue;
+    }
+    if (fused_b0) add(PlanStep::STEM_BLOCK, 0);   // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
+    else {
+      const bool chain = wants_chain(s), chain_s2 = wants_s2(s);   // chain_s2: the stride-2 conv + shortcut join the launch
+      bool sc_c16 = false;
+      if (s == 0) add(PlanStep::STEM5, 0);
+      else if (chain_s2) {}
+      else if (s == 1 && l0_front) sc_c16 = true;   // layer0_stream_kernel<true> wrote t (pool0) and sc (pool1, chunk-major) already
+      else {
+        // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
+        // (t -- the chain's input, fetched by LDS-DMA -- stays NHWC: chunk-major, the stride-2 kernel's stores gained what the chain's
+        // DMA lost, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)
+        sc_c16 = chain && m.planes[s] == 64 && !tn.no_c16 && !ms.exact;  // (the exact kernels write NHWC)
+        add(PlanStep::CONV_S2, s).sc_c16 = sc_c16;
+      }
+      if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
+        const bool out_c16 = !last && !tn.no_c16 && wants_s2(s + 1);
+        // round 5: large batches run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain)
+        const mlt::PackedConv &q2 = mt.blocks[s][0].conv2;
+        const bool stream = s == 1 && !chain_s2 && m.planes[s] == 64 && ho == 32 && sc_c16 && !mt.w2 && !mt.exact && (cls & CLS_L1_STREAM) &&
+                            q2.taps == 9 && q2.kc == 64 && q2.ct == 64 && !last;
+        PlanStep &st = add(stream ? PlanStep::LAYER1_STREAM : PlanStep::CHAIN, s);
+        st.inside_s2 = chain_s2; st.x_c16 = cur_c16; st.sc_c16 = sc_c16; st.y_c16 = out_c16;
+        cur_c16 = out_c16;
+        continue;
+      }
+      add(PlanStep::CONV_B0C2, s);   // b0 = relu(bn2(conv2 t) + sc)
+    }
+    // block 1 (identity shortcut)
+    if (s == 0 && !mt.exact && ho >= 32 && !tn.no_block_fusion) { add(PlanStep::BLOCK32, 0); continue; }  // 32-channel identity block in ONE kernel
+    add(PlanStep::CONV_B1C1, s);
+    PlanStep &st = add(PlanStep::CONV_B1C2, s);
+    st.y_c16 = !last && !tn.no_c16 && wants_s2(s + 1);
+    cur_c16 = st.y_c16;
+  }
+  add(PlanStep::HEADS, m.n_stages - 1);
+  return P;
 }
 
 // the network in the size's main arithmetic: `model` (fast, or exact when that is the configured / calibrated arithmetic), or -- middle
@@ -668,13 +839,32 @@ int run_layer1_stream(mlt_ctx *ctx, const mlt::Block &B0, const mlt::Block &B1, 
 // mback != NULL (hi+lo-weights tiers): the launch UNITS whose bit is set in back_mask (bit 2 s: layer0.0 / the stride-2 conv + shortcut of
 // layer s; bit 2 s + 1: layer0.1 / the three stride-1 convs of layer s) run `mback` (the hi+lo-weights model; same single fp16 activation
 // planes, so the two models' units compose freely), the others `m` (single-pass kernels).
+// mx != NULL (round 4): the units of x_units run `mx` (the EXACT arithmetic's per-conv kernels; a lo plane behind every tensor such a unit
+// writes; a unit that reads a single-plane producer's output takes its lo part as zero).
 int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t *d_org, long org_rs, long org_cs, const int16_t *d_pred,
                 long pred_rs, long pred_cs, const int32_t *d_poc, const int32_t *d_qp, int32_t *d_split, float *d_logits, int32_t *d_flat = nullptr,
                 mlt::Model *mback = nullptr, unsigned back_mask = 0, const GuardTail *tail = nullptr, bool flat_is_clear = false,
                 mlt::Model *mx = nullptr, unsigned x_units = 0, float *d_mag = nullptr) {
   const int S = st.size;
   if (!mx) x_units = 0;
-  int rc = ctx->plan ? MLT_OK : ensure_ws(ctx, ws_per_cu(m, S, x_units != 0) * (size_t)n);   // (plan mode: the workspace is carved from address 0 and never touched)
+  if (!mback) back_mask = 0;
+  NetCfg c;
+  c.S = S; c.m = &m; c.mback = mback; c.mx = mx; c.back_mask = back_mask; c.x_units = x_units;
+  const unsigned cls = batch_class(ctx, c, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, d_flat != nullptr);
+  // the plan: cached per (models, unit masks, batch class) once the size is loaded -- while a load is in flight (the calibration prices candidate tiers and
+  // rebuilds models in place) it is built per call
+  NetPlan fresh;
+  const NetPlan *plan;
+  if (st.loaded && !ctx->plan) {
+    const PlanKey key{&m, mback, mx, back_mask, x_units, cls};
+    auto it = st.plans.find(key);
+    if (it == st.plans.end()) it = st.plans.emplace(key, plan_network(ctx, c, cls)).first;
+    plan = &it->second;
+  } else {
+    fresh = plan_network(ctx, c, cls);
+    plan = &fresh;
+  }
+  int rc = ctx->plan ? MLT_OK : ensure_ws(ctx, ws_per_cu(m, S, x_units != 0) * (size_t)n);   // (plan mode: the workspace is carved from a fake base and never touched)
   if (rc) return rc;
   // carve the workspace
   char *p = ctx->ws;
@@ -695,173 +885,108 @@ int run_network(mlt_ctx *ctx, SizeState &st, mlt::Model &m, int n, const int16_t
     }
   }
   Launch L{ctx};
-  const void *cur = nullptr;
-  int h = S;
-  HeadArgs ha{};
-  // Which stages run as chain / whole-stage launches (fast arithmetic, large launches; small ones keep the per-conv latency
-  // variants: a chain runs its convs one after the other on n workgroups).  Asked for stage s AND for stage s + 1: a stage
-  // whose successor is a whole-stage kernel writes its output chunk-major (ConvArgs.y_c16).
-  const Tuning &tn = tuning();
-  const bool no_chain = tn.no_chain, no_chain_s2 = tn.no_chain_s2, no_c16 = tn.no_c16;
-  const long chain_min_px = tn.lat_pixels;
-  auto model_of = [&](int s, int u) -> mlt::Model & { return ((x_units >> (2 * s + u)) & 1u) ? *mx : (mback && ((back_mask >> (2 * s + u)) & 1u)) ? *mback : m; };
-  auto wants_chain = [&](int s, int h_in) -> bool {
-    if (s <= 0 || s >= m.n_stages || no_chain) return false;
-    const mlt::Model &mm = model_of(s, 1);
-    if (mm.exact || (mm.w2 && !ctx->lds_oob_zero)) return false;  // (the hi+lo-weights chains exist in the padding-from-beyond-the-LDS form only)
-    const int ho = h_in / 2 > 0 ? h_in / 2 : 1;
-    const mlt::PackedConv &c2 = mm.blocks[s][0].conv2;
-    // The 64-channel chain (a 128 KiB sample per workgroup, 8 accumulators per wave; b0 through HBM): 1.19 ms against 3 x 0.40 ms
-    // for the launch itself, but the step gains 4 % (less HBM traffic -> the power-limited chip clocks the other kernels higher).
-    const bool chain64 = tn.chain64;
-    const bool packing_ok = (m.planes[s] == 64 ? (c2.ct == 64 && c2.gt == 9 && chain64) : (c2.ct == 128 && c2.gt == 3)) && (!mm.w2 || c2.lo8 || m.planes[s] == 64);  // what chain_kernel<C> streams
-    return mlt_chain_supported(m.planes[s], ho) && c2.taps == 9 && c2.kc == 64 && packing_ok && (long)n * ho * ho > chain_min_px;
-  };
-  // (the whole-stage form -- stride-2 conv + shortcut inside the launch -- exists for the single pass only: both units of the stage on `m`)
-  auto wants_s2 = [&](int s, int h_in) -> bool {
-    return wants_chain(s, h_in) && !no_chain_s2 && !model_of(s, 0).w2 && !model_of(s, 1).w2 && (ctx->plan ? !model_of(s, 0).blocks[s][0].conv1_s2c.w.empty() : model_of(s, 0).blocks[s][0].conv1_s2c.d_w != nullptr);
-  };
-  bool cur_c16 = false;  // layout of `cur`
-  bool l0_did_s2 = false;  // the layer0 streaming launch carried layer1.0.conv1 + shortcut
-  for (int s = 0; s < m.n_stages; ++s) {
-    int hout = h, h2;
+  const bool quad_ok = (cls & CLS_QUADS) != 0;
+  for (const PlanStep &ps : *plan) {
+    const int s = ps.s;
     const bool last = s == m.n_stages - 1;
-    // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55);
-    // for s == 0 the same kernel also computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
-    mlt::Model &ms = model_of(s, 0);  // (hi+lo-weights tiers: the two-plane model for the units of the mask)
-    mlt::Model &mt = model_of(s, 1);  // second unit: layer0.1, or conv2 of block 0 + block 1 of the later stages
-    mlt::Block &B0 = ms.blocks[s][0];
-    mlt::Block &B0c = (s == 0 ? ms : mt).blocks[s][0];  // the model block 0's conv2 comes from
-    const int ho = h / 2 > 0 ? h / 2 : 1;
+    mlt::Model &ms = c.model_of(s, 0), &mt = c.model_of(s, 1);
+    const int h = c.h_in(s), ho = h / 2 > 0 ? h / 2 : 1;
+    const void *cur = s > 0 ? outs[s - 1] : nullptr;   // the stage input
     // (exact units, round 4: a unit in the exact arithmetic keeps a lo plane behind the tensors it writes and expects one behind those it
     // reads -- a plane of zeros when the producer is a single-plane unit; single-plane units read the hi planes and ignore the offsets)
     const bool ex0 = ms.exact, ex1 = mt.exact;
-    const size_t lo_in = ex0 ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;         // plane bytes of the stage input
-    const size_t lo_st = (ex0 || ex1) ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;                    // plane bytes inside the stage
+    const size_t lo_in = ex0 ? (size_t)n * h * h * (s == 0 ? 32 : m.planes[s - 1]) * 2 : 0;  // plane bytes of the stage input
+    const size_t lo_st = (ex0 || ex1) ? (size_t)n * ho * ho * m.planes[s] * 2 : 0;             // plane bytes inside the stage
     // an exact unit behind a single-plane unit: its input has no lo part (the producer wrote fp16 values): lo offset 0 = "no lo plane, read
     // zeros" (ConvArgs.x_lo_off / res_lo_off)
-    const bool in_has_lo = s > 0 && model_of(s - 1, 1).exact;
+    const bool in_has_lo = s > 0 && c.model_of(s - 1, 1).exact;
+    const bool b0_has_lo = s == 0 ? ex0 : ex1;  // (b0 = pool2 is written by unit 0 of layer0, by unit 1 of the later stages)
+    int hh = 0;
     ConvIO io;
-    io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
-    io.x_lo = in_has_lo ? lo_in : 0; io.y_lo = lo_st; io.ysc_lo = lo_st;
-    const bool no_fuse0 = tn.no_block_fusion;
-    // stem_block_kernel fetches 4-pixel quads with 8-byte loads: planes 8-byte aligned, strides multiples of 4 elements
-    const bool quad_ok = (((uintptr_t)d_org | (uintptr_t)d_pred) & 7) == 0 && ((org_rs | org_cs | pred_rs | pred_cs) & 3) == 0;
-    const bool fused_b0 = s == 0 && !ms.exact && ho >= 32 && !no_fuse0 && quad_ok;
-    if (s == 0 && d_flat && !fused_b0) {
+    switch (ps.kind) {
+    case PlanStep::FLAT_STAT: {
       FlatStatArgs fa{};
       fa.org = d_org; fa.pred = d_pred; fa.org_row_stride = org_rs; fa.org_cu_stride = org_cs; fa.pred_row_stride = pred_rs;
       fa.pred_cu_stride = pred_cs; fa.flat = d_flat; fa.n = n; fa.s_l = ilog2(S);
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if ((rc = L.prof_begin("guard_flat_stat", 0.0, (double)n * S * S * 4, e0, e1))) return rc;
+      plan_note(ctx, {{"flat", d_flat}}, {{"quads", quad_ok}});
       LAUNCH_TRY(ctx, mlt_launch_flat_stat(fa, quad_ok, ctx->stream));
-      if ((rc = L.prof_end(e1))) return rc;
+      rc = L.prof_end(e1);
+      break;
     }
-    // round 5: batches of 128 x 128 CUs run ALL of layer0 in one streaming launch (same bits; a single CU is faster spread over 8 tile workgroups).
-    // Round 6: from 128 CUs on -- the measured crossover (one CU per workgroup on half the chip already beats the tiled launches: docs/KERNEL_NOTES.md,
-    // "Where the streaming launches start to pay": 128 CUs +3 %, 192 CUs +12 %); round 5 had kept 256
-    const int l0_min = tn.l0_stream_min;
-    if (fused_b0 && ho == 64 && !ms.w2 && !mt.exact && !mt.w2 && l0_min > 0 && n >= l0_min) {
-      // ... and with it the stride-2 conv + shortcut that open layer1, when the 64-channel chain follows (it wants sc chunk-major) and layer1's first
-      // unit runs the single pass too: layer0's output then never reaches HBM
-      const bool no_f5 = tn.no_l0_s5;
-      const mlt::Model &m10 = model_of(1, 0);
-      const mlt::PackedConv &c5 = m10.blocks[1][0].conv1;
-      l0_did_s2 = !no_f5 && m.n_stages > 1 && !m10.exact && !m10.w2 && wants_chain(1, 64) && !wants_s2(1, 64) && m.planes[1] == 64 && !no_c16 &&
-                  c5.has_sc && c5.taps == 9 && c5.kc == 32 && c5.ct == 64 && c5.cin == 32 && c5.cout == 64 && c5.stride == 2;
-      if ((rc = run_layer0_stream(ctx, ms, mt, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, outs[s], d_flat, flat_is_clear,
-                                  l0_did_s2 ? &c5 : nullptr, pool[0], pool[1]))) return rc;
-      cur = outs[s];
-      h = ho;
-      continue;
-    }
-    if (fused_b0) {  // raw planes -> b0 in ONE kernel (t and sc never leave the chip)
-      hout = ho;
-      if ((rc = run_stem_block(ctx, ms, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat, flat_is_clear))) return rc;
-    } else {
-      const bool chain = wants_chain(s, h);
-      const bool chain_s2 = wants_s2(s, h);  // the stride-2 conv + shortcut join the launch
-      if (s == 0) {
-        hout = ho;
-        if ((rc = run_stem5(ctx, ms.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st))) return rc;
-      } else if (chain_s2) hout = ho;
-      else if (s == 1 && l0_did_s2) {  // layer0_stream_kernel<true> wrote t (pool[0]) and sc (pool[1], chunk-major) already
-        hout = ho;
-        io.ysc_c16 = true;
-      } else {
-        // the 64-channel chain reads sc as a residual in accumulator order: chunk-major makes that one cache line per lane quad
-        // (t -- the chain's input, fetched by LDS-DMA -- stays NHWC: chunk-major, the stride-2 kernel's stores gained what the chain's
-        // DMA lost, 0.455 -> 0.438 ms against 1.06 -> 1.08 ms)
-        io.ysc_c16 = chain && m.planes[s] == 64 && !no_c16 && !ex0;  // (the exact kernels write NHWC)
-        if ((rc = run_conv(ctx, B0.conv1, n, h, io, &hout))) return rc;
-      }
-      if (chain) {  // rest of the stage (or all of it) in one launch: activations stay in LDS, b0 in registers
-        const bool out_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
-        // round 5: large batches run the 64-channel stage's three stride-1 convs as a streaming launch (same bits as the chain); round 6: from 128 CUs on
-        const int l1_min = tn.l1_stream_min;
-        const mlt::PackedConv &q2 = B0c.conv2;
-        if (s == 1 && !chain_s2 && m.planes[s] == 64 && hout == 32 && io.ysc_c16 && !mt.w2 && !mt.exact && l1_min > 0 && n >= l1_min &&
-            q2.taps == 9 && q2.kc == 64 && q2.ct == 64 && outs[s] && !last) {
-          if ((rc = run_layer1_stream(ctx, B0c, mt.blocks[s][1], n, pool[0], pool[1], outs[s], gaps[s], out_c16))) return rc;
-        } else
-        if ((rc = run_chain3(ctx, B0c, mt.blocks[s][1], n, hout, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], chain_s2 ? cur : nullptr,
-                             cur_c16, out_c16, pool[2], io.ysc_c16))) return rc;
-        cur = outs[s];
-        cur_c16 = out_c16;
-        h = hout;
-        const int hd = s - 1;
-        ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
-        ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
-        continue;
-      }
-      io = ConvIO();
+    case PlanStep::LAYER0_STREAM:
+      rc = run_layer0_stream(ctx, ms, mt, n, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, outs[0], d_flat, flat_is_clear,
+                             ps.front ? &c.model_of(1, 0).blocks[1][0].conv1 : nullptr, pool[0], pool[1]);
+      break;
+    case PlanStep::STEM_BLOCK:
+      rc = run_stem_block(ctx, ms, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[2], d_flat, flat_is_clear);
+      break;
+    case PlanStep::STEM5:
+      // block 0 (stride 2): ONE kernel gives t = relu(bn1(conv1 x)) and sc = bn(conv1x1 x) (arch:44-55); for s == 0 the same kernel also
+      // computes x = stem(raw planes) on the fly (arch:277-278, EncCu.cpp:810-877)
+      rc = run_stem5(ctx, ms.stem, n, S, d_org, org_rs, org_cs, d_pred, pred_rs, pred_cs, pool[0], pool[1], lo_st);
+      break;
+    case PlanStep::CONV_S2:
+      io.x = cur; io.y = pool[0]; io.y_sc = pool[1]; io.relu = true;
+      io.x_lo = in_has_lo ? lo_in : 0; io.y_lo = lo_st; io.ysc_lo = lo_st;
+      io.ysc_c16 = ps.sc_c16;
+      rc = run_conv(ctx, ms.blocks[s][0].conv1, n, h, io, &hh);
+      break;
+    case PlanStep::CHAIN:
+      rc = run_chain3(ctx, mt.blocks[s][0], mt.blocks[s][1], n, ho, pool[0], pool[1], last ? nullptr : outs[s], gaps[s], ps.inside_s2 ? cur : nullptr,
+                      ps.x_c16, ps.y_c16, pool[2], ps.sc_c16);
+      break;
+    case PlanStep::LAYER1_STREAM:
+      rc = run_layer1_stream(ctx, mt.blocks[s][0], mt.blocks[s][1], n, pool[0], pool[1], outs[s], gaps[s], ps.y_c16);
+      break;
+    case PlanStep::CONV_B0C2:
       io.x = pool[0]; io.y = pool[2]; io.res = pool[1]; io.relu = true;  // b0 = relu(bn2(conv2 t) + sc)
       io.x_lo = io.y_lo = io.res_lo = lo_st;
       if (s > 0 && ex1 && !ex0) io.x_lo = io.res_lo = 0;  // t and sc came from a single-plane unit
-      if ((rc = run_conv(ctx, B0c.conv2, n, hout, io, &h2))) return rc;
+      rc = run_conv(ctx, (s == 0 ? ms : mt).blocks[s][0].conv2, n, ho, io, &hh);
+      break;
+    case PlanStep::BLOCK32:
+      rc = run_block32(ctx, mt.blocks[0][1], n, ho, pool[2], outs[0]);
+      break;
+    case PlanStep::CONV_B1C1:
+      io.x = pool[2]; io.y = pool[3]; io.relu = true;
+      io.x_lo = io.y_lo = lo_st;
+      if (!b0_has_lo) io.x_lo = 0;
+      rc = run_conv(ctx, mt.blocks[s][1].conv1, n, ho, io, &hh);
+      break;
+    case PlanStep::CONV_B1C2:
+      io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
+      io.x_lo = io.y_lo = io.res_lo = lo_st;
+      if (!b0_has_lo) io.res_lo = 0;
+      io.y_c16 = ps.y_c16;
+      rc = run_conv(ctx, mt.blocks[s][1].conv2, n, ho, io, &hh);
+      break;
+    case PlanStep::HEADS: {
+      HeadArgs ha{};
+      for (int t = 1; t < m.n_stages; ++t) {   // head t - 1 pools stage t's output
+        const int hd = t - 1, hs = c.h_in(t + 1);
+        ha.gap[hd] = gaps[t]; ha.slots[hd] = gap_slots(hs * hs); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
+        ha.c[hd] = m.planes[t]; ha.hw[hd] = hs * hs; ha.classes[hd] = m.heads[hd].classes;
+      }
+      ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
+      ha.mag = d_mag;
+      if (tail && (n == 1 || tail->next)) {
+        ha.g_next = tail->next;   // (NULL: mlt_predict's slot -- one CU, the count is set outright)
+        ha.g_count = tail->count; ha.g_idx = tail->idx; ha.g_flat = tail->flat; ha.g_flat_thr = tail->flat_thr; ha.g_near_thr = tail->near_thr; ha.g_margin = tail->margin;
+        ha.g_mag_thr = tail->mag_thr;
+      }
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if ((rc = L.prof_begin("heads", 0.0, 0.0, e0, e1))) return rc;
+      plan_note(ctx, {{"gap0", ha.gap[0]}, {"gap1", ha.gap[1]}, {"gap2", ha.gap[2]}, {"gap3", ha.gap[3]}},
+                {{"slots0", ha.slots[0]}, {"slots1", ha.slots[1]}, {"slots2", ha.slots[2]}, {"slots3", ha.slots[3]}, {"c0", ha.c[0]}, {"c1", ha.c[1]}, {"c2", ha.c[2]}, {"c3", ha.c[3]},
+                 {"hw0", ha.hw[0]}, {"hw1", ha.hw[1]}, {"hw2", ha.hw[2]}, {"hw3", ha.hw[3]}, {"heads", ha.n_heads}});
+      LAUNCH_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
+      rc = L.prof_end(e1);
+      break;
     }
-    // block 1 (identity shortcut)
-    mlt::Block &B1 = mt.blocks[s][1];
-    const bool no_fuse = tn.no_block_fusion;
-    if (s == 0 && !mt.exact && hout >= 32 && !no_fuse) {  // 32-channel identity block in ONE kernel
-      if ((rc = run_block32(ctx, B1, n, hout, pool[2], outs[s]))) return rc;
-      cur = outs[s];
-      h = hout;
-      continue;
     }
-    const bool b0_has_lo = s == 0 ? ex0 : ex1;  // (b0 = pool[2] is written by unit 0 of layer0, by unit 1 of the later stages)
-    io = ConvIO();
-    io.x = pool[2]; io.y = pool[3]; io.relu = true;
-    io.x_lo = io.y_lo = lo_st;
-    if (!b0_has_lo) io.x_lo = 0;
-    if ((rc = run_conv(ctx, B1.conv1, n, hout, io, &h2))) return rc;
-    io = ConvIO();
-    io.x = pool[3]; io.y = last ? nullptr : outs[s]; io.res = pool[2]; io.relu = true; io.gap = gaps[s];
-    io.x_lo = io.y_lo = io.res_lo = lo_st;
-    if (!b0_has_lo) io.res_lo = 0;
-    io.y_c16 = !last && !no_c16 && wants_s2(s + 1, hout);
-    if ((rc = run_conv(ctx, B1.conv2, n, hout, io, &h2))) return rc;
-    cur = outs[s];
-    cur_c16 = io.y_c16;
-    h = hout;
-    if (s >= 1) {
-      const int hd = s - 1;
-      ha.gap[hd] = gaps[s]; ha.slots[hd] = gap_slots(h * h); ha.w[hd] = m.heads[hd].d_w; ha.b[hd] = m.heads[hd].d_b;
-      ha.c[hd] = m.planes[s]; ha.hw[hd] = h * h; ha.classes[hd] = m.heads[hd].classes;
-    }
-  }
-  ha.n_heads = m.n_heads; ha.decision_head = st.head_index; ha.poc = d_poc; ha.qp = d_qp; ha.logits = d_logits; ha.split = d_split;
-  ha.mag = d_mag;
-  if (tail && (n == 1 || tail->ticket)) {
-    ha.g_ticket = n == 1 ? nullptr : tail->ticket;
-    ha.g_count = tail->count; ha.g_idx = tail->idx; ha.g_flat = tail->flat; ha.g_flat_thr = tail->flat_thr; ha.g_near_thr = tail->near_thr; ha.g_margin = tail->margin;
-    ha.g_mag_thr = tail->mag_thr;
-  }
-  {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if ((rc = L.prof_begin("heads", 0.0, 0.0, e0, e1))) return rc;
-    LAUNCH_TRY(ctx, mlt_launch_heads(ha, n, ctx->stream));
-    if ((rc = L.prof_end(e1))) return rc;
+    if (rc) return rc;
   }
   return MLT_OK;
 }
@@ -904,7 +1029,7 @@ int guard_slot(mlt_ctx *ctx, int which, int n, int nl, GuardSlot *g) {
   const size_t ints = ((size_t)ctx->guard_cap_n * 4 + 255) / 256 * 256;
   char *base = ctx->guard_dev + (size_t)which * ctx->guard_slot_bytes;
   g->d_flat = (int32_t *)base; g->d_idx = (int32_t *)(base + ints); g->d_count = (int32_t *)(base + 2 * ints);
-  g->d_ticket = g->d_count + 8;   // (inside the 256 bytes reserved for the count)
+  g->phase = &ctx->guard_phase[which];   // (the pair d_count[0 .. 1] sits inside the 256 bytes reserved for the count)
   g->d_lg = (float *)(base + 2 * ints + 256);
   g->d_mag = (float *)(base + 2 * ints + 256 + ((size_t)ctx->guard_cap_n * ctx->guard_cap_nl * 4 + 255) / 256 * 256);
   g->h_count = ctx->guard_host + which;
@@ -941,13 +1066,17 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
     const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, nullptr};
     return run_main(ctx, st, 1, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg, st.flat_guard ? g.d_flat : nullptr, &tail, true);
   }
-  if (!ctx->guard_select_kernel && g.d_ticket) {
-    // round 6: the selection is a tail of the heads kernel for batches as well (unordered list of flagged CUs through an atomic append, the count published by
-    // the last workgroup): one launch and one launch gap less per step
-    const GuardTail tail{g.d_count, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, g.d_ticket};
+  if (!ctx->guard_select_kernel && g.phase) {
+    // round 6: the selection is a tail of the heads kernel for batches as well -- an unordered list of the flagged CUs through an atomic append on a counter that is
+    // zero on entry; the launch zeroes the slot's OTHER counter for the next one (whose predecessor's count has left the device by then: same stream).  One launch and
+    // one launch gap less per step.  (A first version counted finished workgroups to let the last one publish and re-arm a single counter: 4096 same-address atomics
+    // and release fences made the heads launch 0.123 ms instead of 0.030 -- more than the launch it saved.)
+    int32_t *cnt = g.d_count + *g.phase, *next = g.d_count + (*g.phase ^ 1);
+    *g.phase ^= 1;
+    const GuardTail tail{cnt, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, next};
     if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
                        st.flat_guard ? g.d_flat : nullptr, &tail))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(g.h_count, g.d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g.h_count, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
     return MLT_OK;
   }
   float *mg = st.mag_thr > 0.f ? g.d_mag : nullptr;
@@ -1564,6 +1693,7 @@ void unload_size(mlt_ctx *ctx, int si) {
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
   st.model = mlt::Model(); st.model_exact = mlt::Model(); st.model_w2 = mlt::Model(); st.model_xl = mlt::Model();
   st.loaded = false;
+  st.plans.clear();
 }
 
 // Load (or re-calibrate: `extra` = the caller's CUs) ONE device's copy of a size.  blob / bytes stay valid for the call.
@@ -1587,6 +1717,7 @@ int load_one(mlt_ctx *ctx, int size, const void *blob, size_t bytes, const Calib
   // error path below releases what it uploaded, so a failed reload leaves the size cleanly unloaded instead of leaking)
   free_model(st.model); free_model(st.model_exact); free_model(st.model_w2); free_model(st.model_xl);
   st.loaded = false;
+  st.plans.clear();
   st.exact = st.want_exact && !small_mix;
   st.lite = false; st.flat_guard = st.cfg_flat_guard; st.flat_div = 8; st.guard_margin = ctx->guard_margin;
   st.w2 = false; st.w2_mask = 0; st.w2_units = 0; st.x_mask = 0; st.x_units = 0;
@@ -1759,6 +1890,7 @@ int mlt_plan_describe(const void *blob, size_t bytes, int size, int n, int tier,
   mlt_ctx ctx;
   std::vector<std::string> plan;
   ctx.plan = &plan;
+  ctx.plan_detail = (aligned & 2) != 0;   // (bit 1 of `aligned`: every record also lists the launch's buffers -- the hand-offs between launches)
   ctx.lds_oob_zero = true;    // (what every gfx950 device reports: mlt_probe_lds_oob)
   SizeState &st = ctx.sz[si];
   st.size = size; st.enabled = st.loaded = true;
@@ -1771,9 +1903,11 @@ int mlt_plan_describe(const void *blob, size_t bytes, int size, int n, int tier,
   st.exact = whole_exact;
   st.w2 = !whole_exact && w2_units != 0; st.w2_units = st.w2 ? w2_units : 0; st.x_units = whole_exact ? 0 : x_units;
   const long cs = (long)size * size;
-  const int16_t *planes = (const int16_t *)(uintptr_t)(aligned ? 0x1000 : 0x1002);   // never dereferenced: only the alignment is looked at
-  int32_t flat_dummy = 0;
-  const int rc = run_main(&ctx, st, n, planes, size, cs, planes, size, cs, nullptr, nullptr, nullptr, nullptr, whole_exact ? nullptr : &flat_dummy);
+  const int16_t *planes = (const int16_t *)(uintptr_t)((aligned & 1) ? 0x1000 : 0x1002);   // never dereferenced: only the alignment is looked at
+  int32_t *const flat_fake = (int32_t *)(uintptr_t)0x2000;   // (never dereferenced in plan mode; a constant so that the detailed records are reproducible)
+  ctx.ws = (char *)(uintptr_t)0x100000000ull;   // (never touched in plan mode: a base that tells a workspace offset from a NULL pointer in the detailed records)
+  const int rc = run_main(&ctx, st, n, planes, size, cs, planes, size, cs, nullptr, nullptr, nullptr, nullptr, whole_exact ? nullptr : flat_fake);
+  ctx.ws = nullptr;
   if (rc) return -1;
   size_t pos = 0;
   for (const std::string &l : plan) {
@@ -2291,12 +2425,11 @@ int mlt_predict(mlt_ctx *ctx, const int16_t *org, int org_stride, const int16_t 
 // ---- deferred single-CU prediction ----
 namespace {
 // device / pinned layout of one output set: split[CAP] | logits[CAP * nl] | flagged count (16 ints) | flat[CAP] | idx[CAP]
-struct DeferredOut { int32_t *split; float *lg; int32_t *count, *ticket, *flat, *idx; float *mag; };
+struct DeferredOut { int32_t *split; float *lg; int32_t *count, *flat, *idx; float *mag; };
 DeferredOut deferred_out(char *base, int nl) {
   DeferredOut o;
   o.split = (int32_t *)base; o.lg = (float *)(base + (size_t)MLT_DEFER_CAP * 4);
   o.count = (int32_t *)(base + (size_t)MLT_DEFER_CAP * 4 * (1 + nl));
-  o.ticket = o.count + 8;   // (inside the 16 ints reserved for the count; BEHIND the bytes mlt_wait fetches, deferred_fetch_bytes: + 64 covers the 16 ints)
   o.flat = o.count + 16; o.idx = o.flat + MLT_DEFER_CAP; o.mag = (float *)(o.idx + MLT_DEFER_CAP);
   return o;
 }
@@ -2318,7 +2451,7 @@ int deferred_launch(mlt_ctx *ctx, SizeState *st, Deferred &df) {  // launch the 
   int rc;
   if (st->guards()) {
     GuardSlot g;
-    g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.d_mag = od.mag; g.d_ticket = od.ticket; g.h_count = oh.count;
+    g.d_flat = od.flat; g.d_idx = od.idx; g.d_count = od.count; g.d_lg = od.lg; g.d_mag = od.mag; g.phase = &df.phase[b]; g.h_count = oh.count;
     rc = run_guarded_async(ctx, *st, n, pl, d_poc, d_qp, od.split, od.lg, g);
     df.guard_pending[b] = true;
   } else {
@@ -2344,7 +2477,8 @@ int deferred_guard_fixup(mlt_ctx *ctx, SizeState *st, Deferred &df, int b) {
   char *di = df.d_in + (size_t)b * df.in_set, *ho = df.h_out + (size_t)b * df.out_set, *dout = df.d_out + (size_t)b * df.out_set;
   const size_t planes = (size_t)MLT_DEFER_CAP * df.plane;
   const DeferredOut od = deferred_out(dout, nl), oh = deferred_out(ho, nl);
-  const int k = *oh.count;
+  // (the set's two selection counters came back with the results: the launch counted on one and zeroed the other -- GuardSlot.phase -- so their sum is the count)
+  const int k = oh.count[0] + oh.count[1];
   if (k == 0) return MLT_OK;
   if (k < 0 || k > df.n_launched[b] || !st->guards()) { ctx->err = "guard: bad flagged-CU count"; return MLT_ERR_HIP; }
   int32_t *d_poc = (int32_t *)(di + 2 * planes), *d_qp = d_poc + MLT_DEFER_CAP;

@@ -193,11 +193,12 @@ struct HeadArgs {
   // wanted.  g_mag_thr > 0 (single-CU launches): CU 0 is also flagged when its magnitude exceeds the threshold (NaN included).
   float *mag;
   float g_mag_thr;
-  // Round 6: the selection rides on this kernel for BATCHES too (g_ticket != NULL; guard_select_kernel -- a launch of its own, 23 us + a launch gap of a 4 ms step --
-  // stays behind MLT_TUNING=1 MLT_GUARD_SELECT_KERNEL=1).  Every workgroup tests its CU and appends it to g_idx through g_ticket[1] (a running count; the list is
-  // UNORDERED -- the exact re-run treats every CU independently, so the results do not depend on the order); the last workgroup to finish (g_ticket[0] counts them)
-  // publishes the count in g_count[0] and zeroes both words for the next launch (they start at zero: the runtime clears them when it allocates the slot).
-  int32_t *g_ticket;
+  // Round 6: the selection rides on this kernel for BATCHES too (g_next != NULL; guard_select_kernel -- a launch of its own, 23 us + a launch gap of a 4 ms step --
+  // stays behind MLT_TUNING=1 MLT_GUARD_SELECT_KERNEL=1).  g_count[0] is then a running count, ZERO on entry: a workgroup whose CU is flagged appends it to g_idx
+  // (the list is UNORDERED -- the exact re-run treats every CU independently, so the results do not depend on the order); workgroup 0 zeroes g_next[0], the counter
+  // the slot's next launch will count on (the runtime alternates between two counters: the one zeroed here was read by the previous launch's count copy, which
+  // precedes this kernel in stream order).  No atomics, no fences on the unflagged path.
+  int32_t *g_next;
 };
 
 // ---- parity guard (fast arithmetic): device-side selection of the CUs that are re-evaluated with the exact arithmetic ----

@@ -24,6 +24,11 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "ab_select_*.json"))):
 PY
 bash scripts/evidence_run.sh $tag > $out/evidence.log 2>&1; tail -3 $out/evidence.log | cut -c1-400
 timeout 600 python scripts/r06_lite_range_probe.py > $out/lite_range_probe.txt 2>&1; tail -30 $out/lite_range_probe.txt | cut -c1-300
+# the tail probe (>= 300 k logits per weight set over six content classes + natural scenes) of the shipped tiers on the final sources: the seeded set of the headline, the
+# seeded set admitted behind the magnitude guard, the two trained families
+blobs=$(ls tests/data/_blobs/*.mltw 2>/dev/null | tr '\n' ',' | sed 's/,$//')
+timeout 2400 python scripts/tail_probe.py --seeds "10,21" --blobs "$blobs" --natural 4096 > $out/tail_probe.txt 2>&1; echo "tail probe rc $?"
+grep -E "^seed|=>|natural|texture" $out/tail_probe.txt | cut -c1-330 | tail -40
 for grp in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_BUSY_CYCLES SQ_INSTS_LDS"; do
   name=$(echo $grp | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_exact/$name -o out -- python3 scripts/prof_run.py 2048 2 1 > $out/pmc_exact_$name.log 2>&1

@@ -2,7 +2,11 @@
 tier x batch class x alignment x which neighbour is a whole-stage kernel (layouts between them) -- and round 5 left that decision observable only on a
 GPU.  The library's plan mode (mlt_ctx::plan) runs the same code with every launch RECORDED instead of enqueued; mlt_plan_describe (host-only hook, no
 device) returns the list.  Pinned here: the launches of the shipped tiers at the batch classes the encoder and the bench use, and the layout hand-offs
-(chunk-major outputs exactly where the consumer is a whole-stage kernel)."""
+(chunk-major outputs exactly where the consumer is a whole-stage kernel).  Round 6, second half: the decision is a pure function of (models, unit masks,
+batch class) -- plan_network -- whose result the hot path caches and walks; the detailed records (aligned | 2) carry every launch's buffers, so the
+hand-offs between launches (what one writes is what the next reads, lo planes exactly where an exact unit is on either side) are checked here too.
+scripts/plan_matrix.py dumps the detailed plans of ~9000 (size, batch, tier, masks, alignment) cases: the before / after check of a dispatcher change."""
+import re
 import ctypes as C
 
 import pytest
@@ -95,3 +99,53 @@ def test_small_models(plan):
     p = plan(16, 4096, x_units=0x3FC)
     assert names(p)[:2] == ["guard_flat_stat", "stem5x5_s2_2to32_h8+sc"] and all("single pass" in l for l in p[1:5]) and all("[exact" in l for l in p[5:21])
     assert sum("centre tap" in l for l in p) == 7
+
+
+def args(line):
+    """{'x': int, ...} of a detailed record."""
+    m = re.search(r"\{(.*)\}$", line)
+    return {k: int(v, 0) for k, v in (kv.split("=") for kv in m.group(1).split())}
+
+
+def test_buffers_are_handed_from_launch_to_launch(plan):
+    # the four fused launches of a batch: layer0's streaming launch writes t and sc, layer1's reads them; every stage reads its predecessor's output; the heads read
+    # the three GAP buffers the last launches of layer1 .. layer3 wrote
+    p = plan(128, 4096, aligned=3)
+    a = [args(l) for l in p]
+    assert a[0]["y_t"] == a[1]["t"] and a[0]["y_sc"] == a[1]["sc"] and "y" not in a[0]          # layer0's own output never reaches HBM
+    assert a[1]["y"] == a[2]["x"] and a[2]["y"] == a[3]["x"] and "y" not in a[3]                # the last stage writes GAP sums only
+    assert [a[4][f"gap{i}"] for i in range(3)] == [a[1]["gap"], a[2]["gap"], a[3]["gap"]]
+    assert (a[4]["slots0"], a[4]["slots1"], a[4]["slots2"]) == (32, 8, 2) and (a[4]["hw0"], a[4]["hw1"], a[4]["hw2"]) == (1024, 256, 64) and a[4]["heads"] == 3
+    # every buffer of the workspace is distinct where it must be: t, sc, the three stage outputs, the GAP sums
+    bufs = [a[0]["y_t"], a[0]["y_sc"], a[1]["y"], a[2]["y"], a[1]["gap"], a[2]["gap"], a[3]["gap"]]
+    assert len(set(bufs)) == len(bufs)
+    # the one-CU call: a chain of per-conv launches, each reading what the one before wrote; residuals come from two launches back
+    q = [args(l) for l in plan(128, 1, aligned=3)]
+    assert q[1]["x"] == q[0]["y"] and q[2]["x"] == q[1]["y"]
+    for i in (3, 7, 11):                                      # conv2 of block 0: t -> b0, + sc
+        assert q[i]["x"] == q[i - 1]["y"] and q[i]["res"] == q[i - 1]["y_sc"]
+        assert q[i + 1]["x"] == q[i]["y"] and q[i + 2]["x"] == q[i + 1]["y"] and q[i + 2]["res"] == q[i]["y"]   # block 1: conv1, conv2 + b0
+        if i < 11:
+            assert q[i + 3]["x"] == q[i + 2]["y"]             # next stage's stride-2 conv reads the stage output
+    assert "y" not in q[13] and q[14]["gap2"] == q[13]["gap"]
+
+
+def test_lo_planes_exist_exactly_where_an_exact_unit_is_involved(plan):
+    # layer1 hi+lo weights, layer2 + layer3 exact (units 4 .. 7): the exact stride-2 conv of layer2 reads a single-plane tensor (x_lo = 0: "no lo plane") and writes
+    # two planes; inside the exact stages every tensor has its lo plane one plane's bytes behind the hi plane
+    p = plan(128, 4096, tier=4, w2_units=0xC, x_units=0xF0, aligned=3)
+    a = [args(l) for l in p]
+    n = 4096
+    s2 = a[3]
+    assert "exact" in p[3] and s2["x_lo"] == 0 and s2["y_lo"] == s2["ysc_lo"] == n * 16 * 16 * 128 * 2
+    for r in a[4:7]:
+        assert r["x_lo"] == r["y_lo"] == n * 16 * 16 * 128 * 2
+    s2 = a[7]
+    assert s2["x_lo"] == n * 16 * 16 * 128 * 2 and s2["y_lo"] == n * 8 * 8 * 256 * 2      # layer3's input HAS a lo plane (its producer is exact)
+    # the single-plane launches before it carry no lo offsets at all
+    assert a[1]["x_lo"] == a[1]["y_lo"] == a[1]["ysc_lo"] == 0
+    # an exact unit 1 behind a single-plane unit 0 (layer2.s1 exact only): t, sc and the stage input have no lo plane, b0 and everything behind it does
+    q = [args(l) for l in plan(128, 4096, tier=4, x_units=0x20, aligned=3)]
+    convs = [r for r, l in zip(q, plan(128, 4096, tier=4, x_units=0x20, aligned=3)) if "128to128" in l]
+    assert convs[0]["x_lo"] == 0 and convs[0]["res_lo"] == 0 and convs[0]["y_lo"] > 0
+    assert convs[1]["x_lo"] == convs[1]["y_lo"] == convs[0]["y_lo"] and convs[2]["res_lo"] == convs[0]["y_lo"]
