@@ -38,7 +38,8 @@ def per_kernel(path, counter, steps):
             else:
                 name = f"chain{nconv}_s1_{c}_h{1 << hl}(conv2+conv1+conv2)"
         elif "layer0_stream_kernel" in k:  # (the names run_layer0_stream profiles under -- mlt_profile_entry.name holds 47 characters: with / without layer1's stride-2 conv as a fifth stage)
-            name = "layer0_stream_h64(stem+layer0+layer1.0.conv1+sc)"[:47] if "<true>" in k else "layer0_stream_h64(stem+layer0.0+layer0.1)"
+            # (template arguments since round 6: <F5, M16> -- the first one says whether the fifth stage rides along)
+            name = "layer0_stream_h64(stem+layer0+layer1.0.conv1+sc)"[:47] if re.search(r"layer0_stream_kernel<true", k) else "layer0_stream_h64(stem+layer0.0+layer0.1)"
         elif "layer1_stream_kernel" in k:
             name = "layer1_stream_h32(conv2+conv1+conv2)"
         elif "stem_block_kernel" in k:

@@ -1142,7 +1142,8 @@ def test_guard_selection_in_heads_kernel_matches_select_kernel(gpu, monkeypatch)
     """Round 6: a batch's guard selection (flat content, decision margin, logit magnitude) is a tail of the heads kernel -- an unordered list through an
     atomic append, the count published by the last workgroup, both words re-armed for the next launch -- instead of a launch of its own
     (MLT_GUARD_SELECT_KERNEL=1 under MLT_TUNING=1: round 5's guard_select_kernel, ascending list).  Same CUs selected, same bits, on repeated calls of
-    different sizes (the ticket words must come back to zero every time), through the batch, device-pointer and deferred entry points."""
+    different sizes (the counters must come back to zero every time), through the batch, device-pointer and deferred entry points."""
+    import torch
     pkg = gpu
     size = 128
     blob = pkg.weights.synthetic_blob(0, 10)
@@ -1182,6 +1183,74 @@ def test_guard_selection_in_heads_kernel_matches_select_kernel(gpu, monkeypatch)
             s1, l1 = fused.wait(size, t)
             assert s1 == s_all[lo + j] and np.array_equal(l1, l_all[lo + j]), ("deferred", lo + j)
     fused.close(); plain.close()
+
+
+def test_small_guard_reruns_carry_the_same_bits_at_any_count(gpu):
+    """Round 6.  The exact re-run of a FEW flagged CUs (what the encoder's calls and the small models' batches see: k = 1 .. 8) against the same CUs
+    inside a batch with many flagged ones and against the exact arithmetic itself -- repeated calls, several k, a workspace re-allocation in between, every entry
+    point, a caller-owned stream.  (Written for a variant that replayed the re-run's ~20 launches from a hipGraph per (size, k); that variant measured EQUAL --
+    profiles/r06h_ab_rerun_graph.txt: the re-run of one 16 x 16 CU is bound by its kernels, each streaming a whole layer's two weight planes through a handful of
+    workgroups, not by launch overhead -- and was dropped; the test stays.)"""
+    import torch
+    pkg = gpu
+    for size, seed in ((16, 10), (128, 10)):
+        arch = pkg.synth.arch_for_size(size)
+        blob = pkg.weights.synthetic_blob(arch, seed)
+        n = 64
+        org, pred = pkg.synth.make_patches_bulk(size, n, 9301)
+        of, pf = pkg.synth.make_patches(size, 12, 9302, pkg.synth.KIND_FLAT)
+        flat_at = [1, 5, 9, 17, 18, 30, 31, 40, 41, 42, 50, 63]
+        for j, i in enumerate(flat_at):
+            org[i], pred[i] = of[j], pf[j]
+        poc, qp = pkg.synth.make_scalars(n, 9303)
+        m = _ctx(pkg, size, blob, max_batch=256)
+        a = m.arithmetic(size)
+        if a["exact"] == 1:
+            m.close()
+            continue   # (a size the calibration left exact has no guards)
+        r0 = m.arithmetic(size)["guard_reruns"]
+        s_all, l_all = m.predict_batch(org, pred, poc, qp)          # >= 12 flagged: eager re-run
+        assert m.arithmetic(size)["guard_reruns"] - r0 >= 12
+        ex = _ctx(pkg, size, blob, flags=pkg.capi.FLAG_EXACT_128 if size == 128 else pkg.capi.FLAG_NO_CALIBRATION)
+        se, le = ex.predict_batch(org[flat_at], pred[flat_at], poc[flat_at], qp[flat_at])
+        ex.close()
+        assert np.array_equal(l_all[flat_at], le) and np.array_equal(s_all[flat_at], se)
+        for lo, hi in ((0, 4), (0, 8), (0, 16), (16, 20), (38, 44), (0, 4), (16, 20)):   # 1, 2, 3, 2, 3 flat CUs (+ whatever the decision guard adds); repeats replay
+            for rep in range(3):
+                r0 = m.arithmetic(size)["guard_reruns"]
+                s, l = m.predict_batch(org[lo:hi], pred[lo:hi], poc[lo:hi], qp[lo:hi])
+                k = m.arithmetic(size)["guard_reruns"] - r0
+                assert 1 <= k <= 8, (size, lo, hi, k)
+                assert np.array_equal(l, l_all[lo:hi]) and np.array_equal(s, s_all[lo:hi]), (size, lo, hi, rep)
+        # a larger batch re-allocates the workspace: the graphs captured on the old one must not be replayed
+        big_o, big_p = pkg.synth.make_patches_bulk(size, 256, 9304)
+        big_c, big_q = pkg.synth.make_scalars(256, 9304)
+        m.predict_batch(big_o, big_p, big_c, big_q)
+        for rep in range(2):
+            s, l = m.predict_batch(org[0:8], pred[0:8], poc[0:8], qp[0:8])
+            assert np.array_equal(l, l_all[0:8]) and np.array_equal(s, s_all[0:8])
+        # device-pointer entry on torch's stream (a stream the context does not own: the capture runs on the context's own capture stream)
+        dev = torch.device("cuda", 0)
+        d = [torch.from_numpy(np.ascontiguousarray(x[0:16])).to(dev) for x in (org, pred, poc, qp)]
+        d_split = torch.full((16,), -7, dtype=torch.int32, device=dev)
+        d_lg = torch.zeros((16, m.num_logits(size)), dtype=torch.float32, device=dev)
+        m.set_stream(torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            m.predict_batch_device(16, size, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d_split.data_ptr(), d_lg.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_split.cpu().numpy(), s_all[0:16]) and np.array_equal(d_lg.cpu().numpy(), l_all[0:16]), rep
+        m.set_stream(None)
+        # one CU per call and the deferred path
+        for i in (1, 5, 2, 1):
+            s1, l1 = m.predict(org[i], pred[i], int(poc[i]), int(qp[i]))
+            assert s1 == s_all[i] and np.array_equal(l1, l_all[i]), i
+        for rep in range(2):
+            tk = [m.submit(org[i], pred[i], int(poc[i]), int(qp[i])) for i in range(36, 44)]
+            m.flush(size)
+            for j, t in enumerate(tk):
+                s1, l1 = m.wait(size, t)
+                assert s1 == s_all[36 + j] and np.array_equal(l1, l_all[36 + j]), ("deferred", 36 + j)
+        m.close()
 
 
 def test_magnitude_guard(gpu):

@@ -149,3 +149,22 @@ def test_lo_planes_exist_exactly_where_an_exact_unit_is_involved(plan):
     convs = [r for r, l in zip(q, plan(128, 4096, tier=4, x_units=0x20, aligned=3)) if "128to128" in l]
     assert convs[0]["x_lo"] == 0 and convs[0]["res_lo"] == 0 and convs[0]["y_lo"] > 0
     assert convs[1]["x_lo"] == convs[1]["y_lo"] == convs[0]["y_lo"] and convs[2]["res_lo"] == convs[0]["y_lo"]
+
+
+def test_committed_traffic_figures_cover_the_headline_launches(plan, pkg):
+    """bench.py looks a launch's HBM traffic up in profiles/pmc_traffic.json by the name the launch is profiled under (47 characters of it: mlt_kernel_time.name) +
+    "@<batch>".  Round 6's evidence runs r06A .. r06C were post-processed by a script that still mapped layer0_stream_kernel<F5, M16> by its old one-argument
+    template signature and filed the headline's roofline kernel under the four-stage form's name: `roofline.traffic` came out null although the figures were there.
+    Pinned: while the committed file belongs to the tree's sources, every fused launch of the headline batch has its entry."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed traffic figures")
+    tj = json.load(open(path))
+    if tj.get("_meta", {}).get("source_sig") != pkg.build.source_signature():
+        pytest.skip("profiles/pmc_traffic.json was measured on other kernel sources (bench.py then reports traffic = null and says so)")
+    for name in names(plan(128, 4096))[:4]:
+        key = f"{name[:47]}@4096"
+        assert key in tj and tj[key]["hbm_bytes_per_launch"] > 0 and tj[key]["dispatches_averaged"] == 2, key
