@@ -381,7 +381,7 @@ def make_mix_bulk(size: int, n: int, input_seed: int, flat_frac: float = 0.0, na
     return org, pred, is_flat
 
 
-def flat_quad_fraction(org: np.ndarray, pred: np.ndarray, flat_range: int = 8, return_exact: bool = False):
+def flat_quad_fraction(org: np.ndarray, pred: np.ndarray, flat_range: int = 6, return_exact: bool = False):
     """Host restatement of the flat-content guard's statistic (csrc/mlt_kernels.hip: quad_near_flat): per CU, the fraction of aligned
     4-pixel quads that are coherent in BOTH planes the network sees (org clipped to 10 bits, |org - pred| clipped) -- range <= flat_range
     or linear to within one step.  The guard flags a CU when the fraction reaches 1/8."""

@@ -22,19 +22,32 @@ def main():
     ap.add_argument("--size", type=int, default=128, help="CU size (round 4: the small models' calibrated tiers too)")
     ap.add_argument("--blobs", default="", help="comma list of MLTW files probed like seeds (round 5: tools/train_synth_weights.py's trained family)")
     ap.add_argument("--natural", type=int, default=0, help="also N CUs of the natural-statistics class (synth.natural_patches)")
+    ap.add_argument("--near-flat", type=int, default=0, help="also N CUs each of the classes around the flat guard's near-flat rule (round 6: low-contrast texture -- not "
+                    "flagged since MLT_FLAT_RANGE is 4 --, +-1 LSB dither, a near-flat band under 1/2 of the quads)")
     a = ap.parse_args()
     pkg = mltcnn_pkg.load()
     S, size = pkg.synth, a.size
     arch = S.arch_for_size(size)
     classes = [("texture", None), ("uniform", S.KIND_UNIFORM), ("org_flat_pred_tex", S.KIND_ORG_FLAT_PRED_TEX),
                ("org_tex_pred_flat", S.KIND_ORG_TEX_PRED_FLAT), ("partial_flat", S.KIND_PARTIAL_FLAT)]
+    if a.near_flat:
+        classes += [("low_contrast", S.KIND_LOW_CONTRAST), ("dither", S.KIND_DITHER), ("partial_near_flat", S.KIND_PARTIAL_NEAR_FLAT), ("low_contrast_5_6", -2)]
     data = {}
     if a.natural:
         org, pred = S.natural_patches(size, a.natural, 31337)
         poc, qp = S.make_scalars(a.natural, 31337 + 99)
         data["natural"] = (org, pred, poc, qp)
     for name, kind in classes:
-        n = a.n_texture if kind is None else a.n
+        n = a.n_texture if kind is None else (a.near_flat if name in ("low_contrast", "dither", "partial_near_flat", "low_contrast_5_6") else a.n)
+        if kind == -2:   # texture of amplitude 5 / 6 on a constant base (KIND_LOW_CONTRAST is amplitude 4): 45 - 60 % of its quads have a range <= 8, 25 - 40 % <= 6 --
+            rng = np.random.default_rng(31337 + 1000)   # the content MLT_FLAT_RANGE = 6 stops flagging for good
+            amp = 5 + (np.arange(n) % 2)[:, None, None]
+            org = (rng.integers(8, 1016, size=(n, 1, 1)) + rng.integers(-6, 7, size=(n, size, size)).clip(-amp, amp)).clip(0, 1023).astype(np.int16)
+            pred = (org + rng.integers(-2, 3, size=(n, size, size))).clip(0, 1023).astype(np.int16)
+            poc, qp = S.make_scalars(n, 31337 + 1000)
+            data[name] = (org, pred, poc, qp)
+            print(f"generated {name}: {n} CUs (near-flat fraction at range 8 / 6: {S.flat_quad_fraction(org[:64], pred[:64], 8).mean():.2f} / {S.flat_quad_fraction(org[:64], pred[:64], 6).mean():.2f})", flush=True)
+            continue
         org, pred = S.make_patches_bulk(size, n, 31337) if kind is None else S.make_patches(size, n, 31337 + kind, kind)
         poc, qp = S.make_scalars(n, 31337 + (kind or 0))
         data[name] = (org, pred, poc, qp)

@@ -145,7 +145,7 @@ def test_content_classes_against_oracle(gpu, seed):
             check_splits(split, ref, ref_split, sl, name == "default", LOGIT_TOL, (S.KIND_NAMES[kind], name))
     print(f"seed {seed} (tier {tier}):", report)
     if tier != 1:  # the widened guard statistic really catches these classes (exact re-run of every CU)
-        for k in ("dither", "low_contrast", "flat_zero_resi", "ramp"):
+        for k in ("dither", "low_contrast", "flat_zero_resi", "ramp"):   # (round 6: MLT_FLAT_RANGE 8 -> 6 -- amplitude-4 texture is still 69 - 73 % near-flat)
             assert report[(k, "default")][1] == n and report[(k, "no decision guard")][1] == n, (k, report[(k, "default")])
         # partial_flat sits just UNDER the flat guard's 1/8 by construction: it stays on the main arithmetic -- unless the tier was admitted behind the
         # magnitude guard (round 6: seed 21), which runs the flat guard at 1/16 and therefore takes every one of these CUs
