@@ -1072,10 +1072,15 @@ int run_guarded_async(mlt_ctx *ctx, SizeState &st, int n, const Planes &pl, cons
     // one launch gap less per step.  (A first version counted finished workgroups to let the last one publish and re-arm a single counter: 4096 same-address atomics
     // and release fences made the heads launch 0.123 ms instead of 0.030 -- more than the launch it saved.)
     int32_t *cnt = g.d_count + *g.phase, *next = g.d_count + (*g.phase ^ 1);
-    *g.phase ^= 1;
     const GuardTail tail{cnt, g.d_idx, st.flat_guard ? g.d_flat : nullptr, (S * S / 4) / st.flat_div, (S * S / 4) / 2, st.margin_guard ? st.guard_margin : 0.f, st.mag_thr, next};
     if ((rc = run_main(ctx, st, n, pl.org, pl.org_rs, pl.org_cs, pl.pred, pl.pred_rs, pl.pred_cs, d_poc, d_qp, d_split, lg,
-                       st.flat_guard ? g.d_flat : nullptr, &tail))) return rc;
+                       st.flat_guard ? g.d_flat : nullptr, &tail))) {
+      // a pass that failed (e.g. no memory for the workspace of an oversized batch -- the caller may come back with a smaller one) may or may not have run its heads
+      // kernel: both counters back to zero, the phase stays -- whichever counter the next launch counts on is zero on entry
+      (void)hipMemsetAsync(g.d_count, 0, 8, ctx->stream);
+      return rc;
+    }
+    *g.phase ^= 1;
     HIP_TRY(ctx, hipMemcpyAsync(g.h_count, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
     return MLT_OK;
   }
