@@ -2066,7 +2066,11 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
     st.cfg_mag_guard = (cfg->flags & MLT_FLAG_NO_MAGNITUDE_GUARD) == 0;
     // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
     st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
-    st.small_mix = sizes[i] != 128 && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
+    // Round 6: not the 16 x 16 model.  Its layer0 works on 8 x 8 maps -- the single pass there saves 9 % of the exact step -- while any non-exact tier brings the
+    // guards with it, and ONE re-run per 4096-CU batch (the decision guard's usual catch) costs 0.34 ms of a 0.43 ms step: measured 5.30 M CU/s in the
+    // calibrated prefix tier against 8.66 M in the exact arithmetic it is configured for (profiles/r06m_small_exact_vs_prefix.txt); exact also means 2e-5 instead
+    // of 4e-4 from the oracle and no data-dependent latency.  (64 x 64: the prefix tier saves 16 % and a re-run costs 9 %: 1.24 M against 1.05 M -- it stays.)
+    st.small_mix = (sizes[i] == 64 || sizes[i] == 32) && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];

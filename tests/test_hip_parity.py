@@ -449,6 +449,8 @@ def test_small_models_calibrated_prefix(gpu):
             a = m.arithmetic(size)
             print(f"size {size} seed {seed}:", a)
             assert a["exact"] in (1, 4, 5)   # (5, round 5: no prefix passes but the exact-lite arithmetic does -- 64 x 64 with seed 13)
+            if size == 16:   # round 6: the 16 x 16 model is not calibrated down -- a prefix tier saves 9 % of its step and one guard re-run per batch costs 79 %
+                assert a["exact"] == 1 and a["calibrated"] == 0 and a["flat_guard"] == 0 and a["decision_guard"] == 0, a
             seen.add(a["exact"])
             if a["exact"] == 4:
                 # (every stage behind layer0 exact; of layer0 at most one launch unit -- the 64 x 64 model keeps layer0.1 exact)
@@ -1193,7 +1195,7 @@ def test_small_guard_reruns_carry_the_same_bits_at_any_count(gpu):
     workgroups, not by launch overhead -- and was dropped; the test stays.)"""
     import torch
     pkg = gpu
-    for size, seed in ((16, 10), (128, 10)):
+    for size, seed in ((64, 10), (128, 10)):
         arch = pkg.synth.arch_for_size(size)
         blob = pkg.weights.synthetic_blob(arch, seed)
         n = 64
