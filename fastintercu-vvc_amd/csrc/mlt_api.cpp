@@ -2066,11 +2066,15 @@ int init_one(const mlt_config *cfg, int device, mlt_ctx **out) {
     st.cfg_mag_guard = (cfg->flags & MLT_FLAG_NO_MAGNITUDE_GUARD) == 0;
     // the calibration decides "fast or exact" for the 128 model; MLT_FLAG_FAST_SMALL is an explicit request for fast
     st.calibrate = sizes[i] == 128 && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
-    // Round 6: not the 16 x 16 model.  Its layer0 works on 8 x 8 maps -- the single pass there saves 9 % of the exact step -- while any non-exact tier brings the
-    // guards with it, and ONE re-run per 4096-CU batch (the decision guard's usual catch) costs 0.34 ms of a 0.43 ms step: measured 5.30 M CU/s in the
-    // calibrated prefix tier against 8.66 M in the exact arithmetic it is configured for (profiles/r06m_small_exact_vs_prefix.txt); exact also means 2e-5 instead
-    // of 4e-4 from the oracle and no data-dependent latency.  (64 x 64: the prefix tier saves 16 % and a re-run costs 9 %: 1.24 M against 1.05 M -- it stays.)
-    st.small_mix = (sizes[i] == 64 || sizes[i] == 32) && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
+    // Round 6: only the 64 x 64 model.  A non-exact tier brings the guards with it, and a re-run of even ONE CU costs ~0.3 ms whatever the model (the exact chain's ~25
+    // dependent launches, each streaming a layer's weight planes through a few workgroups): a tier must save more than that per batch to be worth having.
+    //   16 x 16: layer0 works on 8 x 8 maps -- the calibrated prefix tier saved 9 % of the exact step and its one re-run per 4096-CU batch (the decision guard's usual
+    //            catch) cost 0.34 ms of 0.43: 5.30 M CU/s against 8.66 M exact (profiles/r06m_small_exact_vs_prefix.txt);
+    //   32 x 32: the exact-lite tier the search ended on is 0.3 - 2 % faster than exact on content that flags nothing and 29 % slower with 5 % flat CUs in the batch
+    //            (2.51 M against 3.53 M, profiles/r06n_small_exact_vs_calibrated.txt);
+    //   64 x 64: layer0.0 on the fused single-pass kernel saves 16 % (1.24 M against 1.05 M exact, also on natural scenes); break-even at ~4 % flagged CUs: it stays.
+    // Exact also means 2e-5 instead of 1e-4 .. 4e-4 from the oracle and no data-dependent latency.
+    st.small_mix = sizes[i] == 64 && st.want_exact && (cfg->flags & MLT_FLAG_NO_CALIBRATION) == 0;
     st.head_index = cfg->head_index[i] >= 0 ? cfg->head_index[i] : (sizes[i] == 128 ? 2 : 0);  // EncCu.cpp:913-919
     if (st.enabled && cfg->weights_dir) {
       char path[1024];

@@ -449,7 +449,8 @@ def test_small_models_calibrated_prefix(gpu):
             a = m.arithmetic(size)
             print(f"size {size} seed {seed}:", a)
             assert a["exact"] in (1, 4, 5)   # (5, round 5: no prefix passes but the exact-lite arithmetic does -- 64 x 64 with seed 13)
-            if size == 16:   # round 6: the 16 x 16 model is not calibrated down -- a prefix tier saves 9 % of its step and one guard re-run per batch costs 79 %
+            if size in (32, 16):   # round 6: only the 64 x 64 model is calibrated down -- at 16 x 16 a prefix tier saves 9 % of the step and one guard re-run per batch costs
+                                   # 79 %; at 32 x 32 the exact-lite tier gains <= 2 % and loses 29 % with 5 % flat CUs in the batch
                 assert a["exact"] == 1 and a["calibrated"] == 0 and a["flat_guard"] == 0 and a["decision_guard"] == 0, a
             seen.add(a["exact"])
             if a["exact"] == 4:
