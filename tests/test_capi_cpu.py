@@ -191,3 +191,28 @@ def test_calibration_set_hook(lib):
     assert all(len(np.unique(pred[i])) == 1 for i in np.flatnonzero(cls == 3)[:8])    # class 3: constant pred
     o2 = np.zeros_like(org)
     assert lib.mlt_calibration_set_copy(S, o2.ctypes.data, None, None, None, None) == 560 and np.array_equal(o2, org)
+
+
+def test_host_restatement_of_the_flat_statistic_uses_the_device_range(pkg):
+    """synth.flat_quad_fraction is the host restatement of the flat-content guard's statistic (probes, flag-rate estimates); its default range must be the
+    device's MLT_FLAT_RANGE (round 6: 6; the near-flat classes of the tests are built around it: amplitude-4 texture 69 - 73 % near-flat, +-1 LSB dither 100 %,
+    natural scenes below 1/2)."""
+    import inspect
+    import os
+    import re
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "fastintercu-vvc_amd", "csrc", "mlt_kernels.h")).read()
+    dev = int(re.search(r"^#define MLT_FLAT_RANGE (\d+)", hdr, re.M).group(1))
+    host = inspect.signature(pkg.synth.flat_quad_fraction).parameters["flat_range"].default
+    assert dev == host == 6
+    S = pkg.synth
+    o, p = S.make_patches(128, 8, 5, S.KIND_LOW_CONTRAST)
+    f = S.flat_quad_fraction(o, p)
+    assert f.min() >= 0.6 and f.max() <= 0.8                      # still flagged (>= 1/2), no longer 100 %
+    o, p = S.make_patches(128, 8, 5, S.KIND_DITHER)
+    assert S.flat_quad_fraction(o, p).min() >= 0.99
+    o, p = S.natural_patches(128, 256, 4242)
+    assert (S.flat_quad_fraction(o, p) >= 0.5).sum() == 0          # (range 8 flagged 2 - 3 % of this class)
+    o, p = S.make_patches(128, 8, 5, S.KIND_PARTIAL_NEAR_FLAT)
+    assert S.flat_quad_fraction(o, p).max() < 0.5
